@@ -1,0 +1,176 @@
+/*
+ * rvseg.h -- C ABI of librvseg.so: the MI355X (gfx950) per-pixel inference path
+ *
+ *     RGB-D frame -> feature_extractor -> libforest random-forest evaluation
+ *                 -> DenseCRF mean-field (permutohedral lattice) -> softmax / argmax
+ *
+ * This is the drop-in boundary for the hot path of VisualComputingInstitute/
+ * RovinaSemanticSegmentation.  The reference has no FFI: the path is reached by ordinary C++
+ * calls from `class Segmenter` (include/segmenter.h:47-69).  Every entry point below names the
+ * reference interface it replaces (paths relative to the reference tree).  Plain pointers and
+ * sizes only; no C++ or torch types cross this boundary; nothing throws across it.
+ *
+ * Memory conventions
+ *   - "host" entry points take host pointers and copy through HBM themselves.
+ *   - "_device" entry points take device (HBM) pointers plus a hipStream_t passed as void*;
+ *     they enqueue work on that stream and return without synchronising.
+ *   - A ctx owns its device buffers, forest copy and LUTs; the caller owns every in/out buffer.
+ *   - One ctx per (thread, device).  Calls on one ctx must be serialised by the caller, exactly
+ *     as the reference serialises its libraries behind _frame_mtx (src/segmenter.cpp:336-435).
+ *
+ * Layouts (identical to the reference's)
+ *   rgb        n x H x W x 3 uint8, channel order as delivered to FeatureExtractor::extract
+ *              (RGB; the R/B swap inside CV_BGR2Lab is part of the trained feature definition,
+ *              include/feature_extractor.h:129, src/test.cpp:130)
+ *   depth_mm   n x H x W uint16, millimetres (include/feature_extractor.h:59-60)
+ *   calib      21 floats: K^-1 (3x3 row-major), R (3x3 row-major), t (3): Calibration::
+ *              _intrinsic_inverse, _extrinsic.linear(), _extrinsic.translation()
+ *              (include/calibration.h:19-21; used at include/feature_extractor.h:223)
+ *   posteriors per frame: layers concatenated, each [y][x][class] float32, offset of layer l =
+ *              sum_{l'<l} H*W*C_l'  (src/segmenter.cpp:413-431; srv/SingleFrameSegmentation.srv
+ *              label_distribution)
+ *   labels     per frame: layers concatenated, each H x W int8
+ *   CRF        unary / Q: N x C float32, class-contiguous per point (= column-major C x N
+ *              Eigen::MatrixXf, third-party/densecrf/include/densecrf.h:56);
+ *              features: N x d float32 (= column-major d x N)
+ */
+#ifndef RVSEG_H
+#define RVSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVSEG_MAX_LAYERS 8
+
+typedef struct rvseg_ctx rvseg_ctx;
+
+typedef enum rvseg_status {
+    RVSEG_OK = 0,
+    RVSEG_ERR_INVALID_ARG = 1, /* bad pointer / size / parameter                                   */
+    RVSEG_ERR_IO = 2,          /* libf::Exception("Could not open file.") (libforest io.h:118-121) */
+    RVSEG_ERR_FORMAT = 3,      /* malformed or inconsistent forest.dat                             */
+    RVSEG_ERR_NO_FOREST = 4,   /* empty forest: the reference asserts (classifier.cpp:168,189),
+                                  compiled out in Release -> UB; here a clean error               */
+    RVSEG_ERR_HIP = 5,         /* HIP runtime failure (message in rvseg_last_error)                */
+    RVSEG_ERR_NO_DEVICE = 6,   /* no gfx950 device: the product never falls back to the CPU        */
+    RVSEG_ERR_CAPACITY = 7     /* lattice hash table / batch capacity exceeded                     */
+} rvseg_status;
+
+/* Label rules found in the reference. */
+typedef enum rvseg_label_mode {
+    RVSEG_LABEL_EVAL = 0,     /* src/test.cpp:160-175: strict '>' from -1000, -1 when nothing wins  */
+    RVSEG_LABEL_CRF = 1,      /* src/segmenter.cpp:646-657: strict '>' from 2.0/C else "Unknown"    */
+    RVSEG_LABEL_NOCRF = 2,    /* src/segmenter.cpp:664-679: strict '>' from -1000, sum!=0 guard     */
+    RVSEG_LABEL_ARGMAX = 3    /* DenseCRF::currentMap, densecrf.cpp:202-211: first maximum          */
+} rvseg_label_mode;
+
+/* Parameter block = the hot-path keys of resources/config.json. */
+typedef struct rvseg_params {
+    int32_t width, height;          /* camera size (Segmenter::_camera_w/_camera_h)                */
+    int32_t stride;                 /* rf_prediction_stride, config.json:87                         */
+    float depth_min, depth_max;     /* config.json:89-90 (metres)                                   */
+    int32_t patch_size;             /* config.json:32                                               */
+    int32_t patch_size_reduce;      /* config.json:34                                               */
+    int32_t feature_color_patch, feature_depth, feature_height, feature_normal; /* config.json:41-44 */
+    float fill_value;               /* low-res image init: 0 (segmenter.cpp:358-362) or -1000
+                                       (test.cpp:143-147)                                           */
+    int32_t use_dense_crf;          /* config.json:81 (per-frame CRF as composed by the north star) */
+    float dcrf_xyz_kernel, dcrf_rgb_kernel, dcrf_kernel_weight; /* config.json:82-84 (multipliers)  */
+    int32_t dcrf_iterations;        /* config.json:85                                               */
+    int32_t multi_layer;            /* 1: multiClassLogPosterior (shared forest, segmenter.cpp:368),
+                                       0: classLogPosterior (test.cpp:151)                          */
+    int32_t label_mode;             /* rvseg_label_mode                                             */
+    int32_t unknown_label[RVSEG_MAX_LAYERS]; /* Segmenter::_layer_unknown_label, segmenter.cpp:88-96 */
+    int32_t max_batch;              /* frames processed per launch group (device buffers are sized
+                                       for this many frames)                                        */
+    int32_t device;                 /* HIP device ordinal                                           */
+    int32_t lattice_capacity_log2;  /* hash-table slots per frame = 2^this (0 = automatic)          */
+} rvseg_params;
+
+/* Fills *p with the defaults of resources/config.json. */
+void rvseg_params_default(rvseg_params *p);
+
+/* Replaces: Segmenter::Segmenter's model/feature set-up (src/segmenter.cpp:106-129) minus ROS.
+ * Fails with RVSEG_ERR_NO_DEVICE when no GPU is present. */
+rvseg_status rvseg_create(const rvseg_params *params, rvseg_ctx **out);
+void rvseg_destroy(rvseg_ctx *ctx);
+/* Message of the last failing call on ctx (or of the last failing rvseg_create if ctx == NULL). */
+const char *rvseg_last_error(const rvseg_ctx *ctx);
+const char *rvseg_status_string(rvseg_status s);
+/* D of the feature vector, include/feature_extractor.h:46-51 (366 with the default config). */
+int32_t rvseg_feature_length(const rvseg_ctx *ctx);
+
+/* ---- forest: replaces libf::RandomForest::read (libforest classifier.cpp:222-235) ------------ */
+rvseg_status rvseg_forest_load(rvseg_ctx *ctx, const char *path);
+rvseg_status rvseg_forest_load_mem(rvseg_ctx *ctx, const void *buf, size_t size);
+/* n_layers / class_counts describe the active mode (multi_layer or single). */
+rvseg_status rvseg_forest_info(const rvseg_ctx *ctx, int32_t *n_trees, int32_t *n_nodes_total,
+                               int32_t *max_depth, int32_t *n_layers,
+                               int32_t class_counts[RVSEG_MAX_LAYERS]);
+/* Replaces: RandomForest::classLogPosterior / multiClassLogPosterior per DataPoint
+ * (libforest classifier.cpp:166-208).  X: P x D host floats; out: P x sumC host floats. */
+rvseg_status rvseg_forest_eval(rvseg_ctx *ctx, const float *X, int32_t P, int32_t D, float *out);
+
+/* ---- features: replaces Features::FeatureExtractor::extract, NO_LABEL branch
+ *      (include/feature_extractor.h:41-291).  Host buffers, one frame.  feat_out: capacity
+ *      (H/stride+1)*(W/stride+1) x D floats; x_v / y_v same capacity.  Exists for parity tests:
+ *      the production path never materialises features. */
+rvseg_status rvseg_extract_features(rvseg_ctx *ctx, const uint8_t *rgb, const uint16_t *depth_mm,
+                                    const float *calib, float *feat_out, int32_t *x_v, int32_t *y_v,
+                                    int32_t *n_points);
+
+/* ---- whole per-frame path: replaces the body of Segmenter::processFramesFromQueueInternalRF
+ *      (src/segmenter.cpp:351-431) and, with use_dense_crf, the DenseCRF call shape of
+ *      Segmenter::processMapFromQueue (src/segmenter.cpp:639-657) applied per frame.
+ *      calib: n x 21 floats (HOST memory in both variants).  Any output pointer may be NULL.
+ *        posteriors_out  n x sumC*H*W   RF log-posteriors (the node's `posteriors` vector)
+ *        marginals_out   n x sumC*H*W   CRF marginals (only with use_dense_crf)
+ *        labels_out      n x L*H*W      labels of the CRF marginals (or of the posteriors
+ *                                       without CRF) under params.label_mode */
+rvseg_status rvseg_segment_frames(rvseg_ctx *ctx, int32_t n_frames, const uint8_t *rgb,
+                                  const uint16_t *depth_mm, const float *calib, float *posteriors_out,
+                                  float *marginals_out, int8_t *labels_out);
+rvseg_status rvseg_segment_frames_device(rvseg_ctx *ctx, int32_t n_frames, const uint8_t *d_rgb,
+                                         const uint16_t *d_depth_mm, const float *calib,
+                                         float *d_posteriors_out, float *d_marginals_out,
+                                         int8_t *d_labels_out, void *hip_stream);
+
+/* ---- CRF: replaces  DenseCRF crf(N,C); crf.setUnaryEnergy(U); crf.addPairwiseEnergy(feat,
+ *      new PottsCompatibility(w)); Q = crf.inference(iters);  (src/segmenter.cpp:641-644;
+ *      densecrf.cpp:54-60,85-91,115-131) with DIAG_KERNEL + NORMALIZE_SYMMETRIC defaults
+ *      (densecrf.h:59).  n_kernels > 1 covers DenseCRF2D::addPairwiseGaussian/Bilateral
+ *      (densecrf.cpp:61-81): kernel k has features[k] (N x ds[k]) and Potts weight ws[k].
+ *      map_out (optional): labels under label_mode / unknown_label. */
+rvseg_status rvseg_crf_infer(rvseg_ctx *ctx, int32_t N, int32_t C, int32_t d,
+                             const float *unary_energy, const float *features, float potts_w,
+                             int32_t iterations, float *Q_out, int8_t *map_out, int32_t label_mode,
+                             int32_t unknown_label);
+rvseg_status rvseg_crf_infer_multi(rvseg_ctx *ctx, int32_t N, int32_t C, int32_t n_kernels,
+                                   const int32_t *ds, const float *const *features, const float *ws,
+                                   const float *unary_energy, int32_t iterations, float *Q_out,
+                                   int8_t *map_out, int32_t label_mode, int32_t unknown_label);
+
+/* ---- lattice introspection for parity tests: Permutohedral::init + compute
+ *      (densecrf permutohedral.cpp:140-321,596-603).  offsets_out / bary_out: N x (d+1);
+ *      keys_out: capacity M_cap x d int16; vertex numbering is arbitrary (results do not depend on
+ *      it); M_out receives the number of lattice vertices. */
+rvseg_status rvseg_lattice_build(rvseg_ctx *ctx, const float *features, int32_t N, int32_t d,
+                                 int32_t *offsets_out, float *bary_out, int16_t *keys_out,
+                                 int32_t keys_capacity, int32_t *M_out);
+/* filter one value matrix (N x C) through the lattice last built on this ctx */
+rvseg_status rvseg_lattice_filter(rvseg_ctx *ctx, const float *in, int32_t C, float *out);
+
+/* ---- timing of the last segment_frames / crf_infer call, measured with HIP events on the
+ *      stream the kernels ran on.  names_out receives a ';'-separated list of stage names,
+ *      ms_out up to max_stages durations.  Returns the number of stages. */
+int32_t rvseg_last_timing(const rvseg_ctx *ctx, char *names_out, size_t names_cap, float *ms_out,
+                          int32_t max_stages);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVSEG_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of librvseg.so (include/rvseg.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this module without a built
+librvseg.so raises; creating a context without a GPU raises RvsegError(NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvseg.so")
+
+RVSEG_MAX_LAYERS = 8
+
+OK, ERR_INVALID_ARG, ERR_IO, ERR_FORMAT, ERR_NO_FOREST, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(8)
+LABEL_EVAL, LABEL_CRF, LABEL_NOCRF, LABEL_ARGMAX = range(4)
+
+# every symbol include/rvseg.h declares
+SYMBOLS = [
+    "rvseg_params_default", "rvseg_create", "rvseg_destroy", "rvseg_last_error",
+    "rvseg_status_string", "rvseg_feature_length", "rvseg_forest_load", "rvseg_forest_load_mem",
+    "rvseg_forest_info", "rvseg_forest_eval", "rvseg_extract_features", "rvseg_segment_frames",
+    "rvseg_segment_frames_device", "rvseg_crf_infer", "rvseg_crf_infer_multi",
+    "rvseg_lattice_build", "rvseg_lattice_filter", "rvseg_last_timing",
+]
+
+
+class RvsegParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+        ("depth_min", C.c_float), ("depth_max", C.c_float),
+        ("patch_size", C.c_int32), ("patch_size_reduce", C.c_int32),
+        ("feature_color_patch", C.c_int32), ("feature_depth", C.c_int32),
+        ("feature_height", C.c_int32), ("feature_normal", C.c_int32),
+        ("fill_value", C.c_float),
+        ("use_dense_crf", C.c_int32),
+        ("dcrf_xyz_kernel", C.c_float), ("dcrf_rgb_kernel", C.c_float),
+        ("dcrf_kernel_weight", C.c_float), ("dcrf_iterations", C.c_int32),
+        ("multi_layer", C.c_int32), ("label_mode", C.c_int32),
+        ("unknown_label", C.c_int32 * RVSEG_MAX_LAYERS),
+        ("max_batch", C.c_int32), ("device", C.c_int32), ("lattice_capacity_log2", C.c_int32),
+    ]
+
+
+class RvsegError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("rvseg status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Loads librvseg.so.  torch (if it is going to be used in this process) must be imported
+    first so that both share one HIP runtime (same soname libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "librvseg.so is not built (run `python __graft_entry__.py` or "
+            "`make -C rovinasemanticsegmentation_amd/csrc`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32 = C.c_void_p, C.c_int32, C.c_float
+    PP = C.POINTER(RvsegParams)
+    L.rvseg_params_default.argtypes = [PP]
+    L.rvseg_params_default.restype = None
+    L.rvseg_create.argtypes = [PP, C.POINTER(vp)]
+    L.rvseg_destroy.argtypes = [vp]
+    L.rvseg_destroy.restype = None
+    L.rvseg_last_error.argtypes = [vp]
+    L.rvseg_last_error.restype = C.c_char_p
+    L.rvseg_status_string.argtypes = [C.c_int]
+    L.rvseg_status_string.restype = C.c_char_p
+    L.rvseg_feature_length.argtypes = [vp]
+    L.rvseg_forest_load.argtypes = [vp, C.c_char_p]
+    L.rvseg_forest_load_mem.argtypes = [vp, vp, C.c_size_t]
+    L.rvseg_forest_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                                    C.POINTER(i32 * RVSEG_MAX_LAYERS)]
+    L.rvseg_forest_eval.argtypes = [vp, vp, i32, i32, vp]
+    L.rvseg_extract_features.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)]
+    L.rvseg_segment_frames.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.rvseg_segment_frames_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.rvseg_crf_infer.argtypes = [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, i32]
+    L.rvseg_crf_infer_multi.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32]
+    L.rvseg_lattice_build.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]
+    L.rvseg_lattice_filter.argtypes = [vp, vp, i32, vp]
+    L.rvseg_last_timing.argtypes = [vp, C.c_char_p, C.c_size_t, vp, i32]
+    for name in SYMBOLS:
+        getattr(L, name)  # raises AttributeError if the library does not export it
+    _lib = L
+    return L
+
+
+def default_params(**kw):
+    p = RvsegParams()
+    lib().rvseg_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "unknown_label":
+            for i, u in enumerate(v):
+                p.unknown_label[i] = int(u)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def check(ctx, status):
+    if status != OK:
+        msg = lib().rvseg_last_error(ctx)
+        raise RvsegError(status, (msg or b"").decode("utf-8", "replace") or
+                         lib().rvseg_status_string(status).decode())

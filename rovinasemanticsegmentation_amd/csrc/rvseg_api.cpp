@@ -1,0 +1,313 @@
+// C-ABI entry points that do not belong to the frame / CRF pipelines: context life cycle, forest
+// loading, the unit-parity forest evaluation, timing read-back.  See include/rvseg.h for the
+// reference interface each one replaces.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+
+#include "rvseg_internal.h"
+
+namespace rvseg {
+
+static std::mutex g_create_err_mtx;
+static std::string g_create_err;
+
+bool hip_ok(rvseg_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    if (ctx) ctx->err = msg;
+    else { std::lock_guard<std::mutex> g(g_create_err_mtx); g_create_err = msg; }
+    return false;
+}
+
+rvseg_status dev_alloc(rvseg_ctx* ctx, DevBuf& b, size_t bytes) {
+    dev_free(b);
+    if (bytes == 0) bytes = 16;
+    RV_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RVSEG_OK;
+}
+
+void dev_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+rvseg_status dev_reserve(rvseg_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return RVSEG_OK;
+    return dev_alloc(ctx, b, bytes);
+}
+
+// ---- Lab tables: OpenCV 2.4 RGB2Lab_b constants (imgproc/color.cpp), see DESIGN.md ------------
+static void build_lab_tables(uint16_t gamma[256], uint16_t cbrt_tab[3072], int coeffs[9]) {
+    auto sat16 = [](long v) { return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); };
+    for (int i = 0; i < 256; i++) {
+        float x = i * (1.f / 255.f);
+        float g = x <= 0.04045f ? x * (1.f / 12.92f) : (float)std::pow((double)(x + 0.055) * (1. / 1.055), 2.4);
+        gamma[i] = sat16(std::lrintf(255.f * 8 * g));
+    }
+    for (int i = 0; i < 3072; i++) {
+        float x = i * (1.f / (255.f * 8));
+        float v = x < 0.008856f ? x * 7.787f + 0.13793103448275862f : std::cbrt(x);
+        cbrt_tab[i] = sat16(std::lrintf(32768.f * v));
+    }
+    static const float xyz[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f,
+                                 0.072169f, 0.019334f, 0.119193f, 0.950227f};
+    static const float white[3] = {0.950456f, 1.f, 1.088754f};
+    const float scale[3] = {4096.f / white[0], 4096.f, 4096.f / white[2]};
+    for (int i = 0; i < 3; i++) {  // blueIdx = 0 (CV_BGR2Lab): the "R" coefficient meets channel 2
+        coeffs[i * 3 + 2] = (int)std::lrint((double)(xyz[i * 3] * scale[i]));
+        coeffs[i * 3 + 1] = (int)std::lrint((double)(xyz[i * 3 + 1] * scale[i]));
+        coeffs[i * 3 + 0] = (int)std::lrint((double)(xyz[i * 3 + 2] * scale[i]));
+    }
+}
+
+static int feature_length_of(const rvseg_params& p) {  // feature_extractor.h:46-51
+    int n = 0;
+    if (p.feature_color_patch) n += p.patch_size_reduce * p.patch_size_reduce * 3;
+    if (p.feature_depth) n += 1;
+    if (p.feature_height) n += 1;
+    if (p.feature_normal) n += 1;
+    return n;
+}
+
+static rvseg_status upload_forest(rvseg_ctx* ctx) {
+    const ForestModel& m = ctx->host_forest;
+    DeviceForest& f = ctx->forest;
+    const bool multi = ctx->params.multi_layer != 0;
+    if (multi && m.layer_classes.empty()) {
+        ctx->err = "params.multi_layer is set but the forest carries no multi-layer histograms";
+        return RVSEG_ERR_FORMAT;
+    }
+    if (!multi && m.single_classes == 0) {
+        ctx->err = "params.multi_layer is 0 but the forest carries no single-label histograms";
+        return RVSEG_ERR_FORMAT;
+    }
+    f.n_trees = m.n_trees;
+    f.max_depth = m.max_depth;
+    f.n_nodes = (int)m.nodes.size();
+    f.n_leaves = m.n_leaves;
+    if (multi) {
+        if (m.layer_classes.size() > RVSEG_MAX_LAYERS) { ctx->err = "too many label layers"; return RVSEG_ERR_FORMAT; }
+        f.n_layers = (int)m.layer_classes.size();
+        f.sum_classes = 0;
+        for (int l = 0; l < f.n_layers; l++) { f.class_counts[l] = m.layer_classes[l]; f.sum_classes += m.layer_classes[l]; }
+    } else {
+        f.n_layers = 1;
+        f.class_counts[0] = m.single_classes;
+        f.sum_classes = m.single_classes;
+    }
+    if (f.sum_classes > 64) { ctx->err = "more than 64 classes over all layers is not supported"; return RVSEG_ERR_FORMAT; }
+    const std::vector<float>& hist = multi ? m.multi_hist : m.single_hist;
+    rvseg_status st;
+    if ((st = dev_alloc(ctx, f.nodes, m.nodes.size() * sizeof(DeviceNode))) != RVSEG_OK) return st;
+    if ((st = dev_alloc(ctx, f.roots, m.roots.size() * sizeof(int32_t))) != RVSEG_OK) return st;
+    if ((st = dev_alloc(ctx, f.hist, hist.size() * sizeof(float))) != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpy(f.nodes.p, m.nodes.data(), m.nodes.size() * sizeof(DeviceNode), hipMemcpyHostToDevice));
+    RV_HIP(ctx, hipMemcpy(f.roots.p, m.roots.data(), m.roots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    RV_HIP(ctx, hipMemcpy(f.hist.p, hist.data(), hist.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->forest_loaded = true;
+    return RVSEG_OK;
+}
+
+}  // namespace rvseg
+
+using namespace rvseg;
+
+extern "C" {
+
+void rvseg_params_default(rvseg_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->width = 640; p->height = 480;
+    p->stride = 2;                                   // config.json:87
+    p->depth_min = 0.5f; p->depth_max = 15.0f;       // config.json:89-90
+    p->patch_size = 77; p->patch_size_reduce = 11;   // config.json:32,34
+    p->feature_color_patch = p->feature_depth = p->feature_height = p->feature_normal = 1;
+    p->fill_value = 0.0f;                            // segmenter.cpp:358-362
+    p->use_dense_crf = 0;                            // config.json:81
+    p->dcrf_xyz_kernel = 0.5f; p->dcrf_rgb_kernel = 4.0f; p->dcrf_kernel_weight = 10.0f;
+    p->dcrf_iterations = 10;                         // config.json:85
+    p->multi_layer = 1;                              // segmenter.cpp:368
+    p->label_mode = RVSEG_LABEL_ARGMAX;
+    p->unknown_label[0] = 7; p->unknown_label[1] = 8;  // "Unknown" of material / object, config.json:59,73
+    p->max_batch = 8;
+    p->device = 0;
+    p->lattice_capacity_log2 = 0;
+}
+
+const char* rvseg_status_string(rvseg_status s) {
+    switch (s) {
+        case RVSEG_OK: return "ok";
+        case RVSEG_ERR_INVALID_ARG: return "invalid argument";
+        case RVSEG_ERR_IO: return "could not open file";
+        case RVSEG_ERR_FORMAT: return "malformed forest";
+        case RVSEG_ERR_NO_FOREST: return "no forest loaded";
+        case RVSEG_ERR_HIP: return "HIP runtime error";
+        case RVSEG_ERR_NO_DEVICE: return "no HIP device";
+        case RVSEG_ERR_CAPACITY: return "capacity exceeded";
+    }
+    return "unknown";
+}
+
+const char* rvseg_last_error(const rvseg_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> g(g_create_err_mtx);
+    static thread_local std::string copy;
+    copy = g_create_err;
+    return copy.c_str();
+}
+
+rvseg_status rvseg_create(const rvseg_params* params, rvseg_ctx** out) {
+    auto fail = [](rvseg_status st, const std::string& msg) {
+        std::lock_guard<std::mutex> g(g_create_err_mtx);
+        g_create_err = msg;
+        return st;
+    };
+    if (!params || !out) return fail(RVSEG_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    const rvseg_params& p = *params;
+    if (p.width < 4 || p.height < 4 || p.width > 16384 || p.height > 16384) return fail(RVSEG_ERR_INVALID_ARG, "bad image size");
+    if (p.stride < 1 || p.stride > 64) return fail(RVSEG_ERR_INVALID_ARG, "bad stride");
+    if (!(p.depth_min > 0.f) || !(p.depth_max >= p.depth_min)) return fail(RVSEG_ERR_INVALID_ARG, "bad depth range");
+    if (p.patch_size_reduce < 1 || p.patch_size_reduce > 32 || p.patch_size < 1) return fail(RVSEG_ERR_INVALID_ARG, "bad patch size");
+    // The reflected border is patch_size wide (feature_extractor.h:37,130): the largest ROI half
+    // size int(patch_size / (2*depth_min)) must fit into it, and a single reflection must do.
+    if (p.feature_color_patch) {
+        int half_max = (int)(p.patch_size / (2.0 * p.depth_min));
+        if (half_max > p.patch_size || p.patch_size > p.width || p.patch_size > p.height)
+            return fail(RVSEG_ERR_INVALID_ARG, "patch ROI would leave the reflected border (depth_min too small or image too small)");
+    }
+    if (p.max_batch < 1 || p.max_batch > 4096) return fail(RVSEG_ERR_INVALID_ARG, "bad max_batch");
+    if (p.label_mode < 0 || p.label_mode > 3) return fail(RVSEG_ERR_INVALID_ARG, "bad label_mode");
+    if (p.dcrf_iterations < 0) return fail(RVSEG_ERR_INVALID_ARG, "bad dcrf_iterations");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(RVSEG_ERR_NO_DEVICE, "no HIP device available: librvseg has no CPU fallback");
+    if (p.device < 0 || p.device >= ndev) return fail(RVSEG_ERR_INVALID_ARG, "device ordinal out of range");
+    if (!hip_ok(nullptr, hipSetDevice(p.device), "hipSetDevice")) return RVSEG_ERR_HIP;
+
+    rvseg_ctx* ctx = new rvseg_ctx();
+    ctx->params = p;
+    ctx->feature_length = feature_length_of(p);
+    if (!hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        delete ctx;
+        return RVSEG_ERR_HIP;
+    }
+    uint16_t gamma[256], cbrt_tab[3072];
+    build_lab_tables(gamma, cbrt_tab, ctx->lab.coeffs);
+    rvseg_status st;
+    if ((st = dev_alloc(ctx, ctx->lab.gamma, sizeof(gamma))) != RVSEG_OK ||
+        (st = dev_alloc(ctx, ctx->lab.cbrt, sizeof(cbrt_tab))) != RVSEG_OK ||
+        !hip_ok(ctx, hipMemcpy(ctx->lab.gamma.p, gamma, sizeof(gamma), hipMemcpyHostToDevice), "upload gamma") ||
+        !hip_ok(ctx, hipMemcpy(ctx->lab.cbrt.p, cbrt_tab, sizeof(cbrt_tab), hipMemcpyHostToDevice), "upload cbrt")) {
+        fail(RVSEG_ERR_HIP, ctx->err);
+        rvseg_destroy(ctx);
+        return RVSEG_ERR_HIP;
+    }
+    *out = ctx;
+    return RVSEG_OK;
+}
+
+void rvseg_pipeline_destroy(rvseg_ctx* ctx);  // rvseg_pipeline.hip
+
+void rvseg_destroy(rvseg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->params.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rvseg_pipeline_destroy(ctx);
+    dev_free(ctx->forest.nodes);
+    dev_free(ctx->forest.roots);
+    dev_free(ctx->forest.hist);
+    dev_free(ctx->lab.gamma);
+    dev_free(ctx->lab.cbrt);
+    for (auto& b : ctx->pool) dev_free(b);
+    for (auto ev : ctx->timer.events) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t rvseg_feature_length(const rvseg_ctx* ctx) { return ctx ? ctx->feature_length : 0; }
+
+rvseg_status rvseg_forest_load_mem(rvseg_ctx* ctx, const void* buf, size_t size) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!buf) { ctx->err = "null forest buffer"; return RVSEG_ERR_INVALID_ARG; }
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    ForestModel m;
+    std::string err;
+    if (!parse_forest(buf, size, ctx->feature_length, m, err)) {
+        ctx->err = err;
+        return m.n_trees == 0 && err == "forest has no trees" ? RVSEG_ERR_NO_FOREST : RVSEG_ERR_FORMAT;
+    }
+    ctx->host_forest = std::move(m);
+    ctx->forest_loaded = false;
+    return upload_forest(ctx);
+}
+
+rvseg_status rvseg_forest_load(rvseg_ctx* ctx, const char* path) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!path) { ctx->err = "null path"; return RVSEG_ERR_INVALID_ARG; }
+    std::ifstream is(path, std::ios::binary);
+    if (!is.is_open()) { ctx->err = std::string("Could not open file. (") + path + ")"; return RVSEG_ERR_IO; }
+    std::vector<char> data((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+    return rvseg_forest_load_mem(ctx, data.data(), data.size());
+}
+
+rvseg_status rvseg_forest_info(const rvseg_ctx* ctx, int32_t* n_trees, int32_t* n_nodes_total,
+                               int32_t* max_depth, int32_t* n_layers,
+                               int32_t class_counts[RVSEG_MAX_LAYERS]) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) return RVSEG_ERR_NO_FOREST;
+    if (n_trees) *n_trees = ctx->forest.n_trees;
+    if (n_nodes_total) *n_nodes_total = ctx->forest.n_nodes;
+    if (max_depth) *max_depth = ctx->forest.max_depth;
+    if (n_layers) *n_layers = ctx->forest.n_layers;
+    if (class_counts)
+        for (int l = 0; l < RVSEG_MAX_LAYERS; l++) class_counts[l] = l < ctx->forest.n_layers ? ctx->forest.class_counts[l] : 0;
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_forest_eval(rvseg_ctx* ctx, const float* X, int32_t P, int32_t D, float* out) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) { ctx->err = "no forest loaded"; return RVSEG_ERR_NO_FOREST; }
+    if (P < 0 || !out || (!X && P > 0)) { ctx->err = "bad arguments"; return RVSEG_ERR_INVALID_ARG; }
+    if (D != ctx->feature_length) { ctx->err = "D does not match the configured feature length"; return RVSEG_ERR_INVALID_ARG; }
+    if (P == 0) return RVSEG_OK;
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    DevBuf dX, dO;
+    rvseg_status st;
+    const size_t S = (size_t)ctx->forest.sum_classes;
+    if ((st = dev_alloc(ctx, dX, (size_t)P * D * sizeof(float))) != RVSEG_OK) return st;
+    if ((st = dev_alloc(ctx, dO, (size_t)P * S * sizeof(float))) != RVSEG_OK) { dev_free(dX); return st; }
+    rvseg_status rc = RVSEG_OK;
+    do {
+        if (!hip_ok(ctx, hipMemcpyAsync(dX.p, X, (size_t)P * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "H2D X")) { rc = RVSEG_ERR_HIP; break; }
+        launch_forest_eval(ctx->forest, dX.as<float>(), P, D, dO.as<float>(), ctx->stream);
+        if (!hip_ok(ctx, hipGetLastError(), "forest_eval launch")) { rc = RVSEG_ERR_HIP; break; }
+        if (!hip_ok(ctx, hipMemcpyAsync(out, dO.p, (size_t)P * S * sizeof(float), hipMemcpyDeviceToHost, ctx->stream), "D2H out")) { rc = RVSEG_ERR_HIP; break; }
+        if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) { rc = RVSEG_ERR_HIP; break; }
+    } while (0);
+    dev_free(dX);
+    dev_free(dO);
+    return rc;
+}
+
+int32_t rvseg_last_timing(const rvseg_ctx* ctx, char* names_out, size_t names_cap, float* ms_out, int32_t max_stages) {
+    if (!ctx) return 0;
+    const auto& t = ctx->timer;
+    std::string joined;
+    for (size_t i = 0; i < t.names.size(); i++) { if (i) joined += ';'; joined += t.names[i]; }
+    if (names_out && names_cap) {
+        std::snprintf(names_out, names_cap, "%s", joined.c_str());
+    }
+    int n = (int)t.ms.size();
+    for (int i = 0; i < n && i < max_stages; i++) if (ms_out) ms_out[i] = t.ms[i];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Internal declarations shared by the C-ABI translation unit and the HIP kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rvseg.h"
+#include "forest_model.h"
+
+namespace rvseg {
+
+// ---------------------------------------------------------------------------------------------
+// device buffer with explicit ownership
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device-side forest (breadth-first node array in HBM, leaf histogram table)
+// ---------------------------------------------------------------------------------------------
+struct DeviceForest {
+    int n_trees = 0;
+    int max_depth = 0;
+    int n_nodes = 0;
+    int n_leaves = 0;
+    int n_layers = 0;                       // layers of the ACTIVE mode
+    int class_counts[RVSEG_MAX_LAYERS] = {}; // per layer
+    int sum_classes = 0;                    // S
+    DevBuf nodes;                           // DeviceNode[n_nodes]
+    DevBuf roots;                           // int32[n_trees]
+    DevBuf hist;                            // float[n_leaves * S] of the active mode
+};
+
+// Lab LUTs (gamma, cube root, 3x3 fixed-point matrix), uploaded once
+struct LabTables {
+    DevBuf gamma;   // uint16[256]
+    DevBuf cbrt;    // uint16[3072]
+    int coeffs[9];
+};
+
+struct StageTimer {
+    std::vector<std::string> names;
+    std::vector<hipEvent_t> events;  // events[i] .. events[i+1] bracket stage i
+    std::vector<float> ms;
+};
+
+}  // namespace rvseg
+
+struct rvseg_ctx {
+    rvseg_params params{};
+    int feature_length = 0;
+    std::string err;
+    rvseg::ForestModel host_forest;
+    bool forest_loaded = false;
+    rvseg::DeviceForest forest;
+    rvseg::LabTables lab;
+    hipStream_t stream = nullptr;  // ctx-owned stream for the host entry points
+    // workspace: grows on demand, owned by the ctx
+    std::vector<rvseg::DevBuf> pool;
+    rvseg::StageTimer timer;
+    struct Impl;
+    Impl* impl = nullptr;  // frame / crf pipeline state (rvseg_pipeline.hip)
+};
+
+namespace rvseg {
+
+// Error plumbing: every HIP call goes through this; failures land in ctx->err.
+bool hip_ok(rvseg_ctx* ctx, hipError_t e, const char* what);
+#define RV_HIP(ctx, call)                                           \
+    do {                                                            \
+        if (!::rvseg::hip_ok((ctx), (call), #call)) return RVSEG_ERR_HIP; \
+    } while (0)
+
+rvseg_status dev_alloc(rvseg_ctx* ctx, DevBuf& b, size_t bytes);
+void dev_free(DevBuf& b);
+// grow-only allocation: reallocates when the buffer is too small
+rvseg_status dev_reserve(rvseg_ctx* ctx, DevBuf& b, size_t bytes);
+
+// ---- kernels_rf.hip --------------------------------------------------------------------------
+// P points with materialised D-dimensional features -> P x S log-posteriors
+void launch_forest_eval(const DeviceForest& f, const float* d_X, int P, int D, float* d_out,
+                        hipStream_t s);
+
+}  // namespace rvseg

@@ -1,0 +1,13 @@
+// placeholder: frame / CRF pipelines (filled in next)
+#include "rvseg_internal.h"
+extern "C" {
+void rvseg_pipeline_destroy(rvseg_ctx*) {}
+#define NOT_YET(ctx) do { if (ctx) (ctx)->err = "not implemented yet"; return RVSEG_ERR_INVALID_ARG; } while (0)
+rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t*, const uint16_t*, const float*, float*, int32_t*, int32_t*, int32_t*) { NOT_YET(ctx); }
+rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t, const uint8_t*, const uint16_t*, const float*, float*, float*, int8_t*) { NOT_YET(ctx); }
+rvseg_status rvseg_segment_frames_device(rvseg_ctx* ctx, int32_t, const uint8_t*, const uint16_t*, const float*, float*, float*, int8_t*, void*) { NOT_YET(ctx); }
+rvseg_status rvseg_crf_infer(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const float*, const float*, float, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
+rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const int32_t*, const float* const*, const float*, const float*, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
+rvseg_status rvseg_lattice_build(rvseg_ctx* ctx, const float*, int32_t, int32_t, int32_t*, float*, int16_t*, int32_t, int32_t*) { NOT_YET(ctx); }
+rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float*, int32_t, float*) { NOT_YET(ctx); }
+}

@@ -1,0 +1,263 @@
+"""Host-side Python mirror of the reference's call shapes for the hot path, over the C ABI.
+
+Names follow the reference so that the parity tests read like its call sites:
+
+  RandomForest.read / classLogPosterior / multiClassLogPosterior   (libforest classifiers.h:274-344)
+  FeatureExtractor.extract                                         (include/feature_extractor.h:41)
+  DenseCRF(N, C).setUnaryEnergy / addPairwiseEnergy / inference / map  (densecrf.h:36-121)
+  Segmenter.processFrames                                          (src/segmenter.cpp:323-443)
+
+All compute happens in librvseg.so (HIP, gfx950).  Nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """Owns one rvseg_ctx (one per thread and device, as include/rvseg.h requires)."""
+
+    def __init__(self, **params):
+        self.params = capi.default_params(**params)
+        h = C.c_void_p()
+        st = capi.lib().rvseg_create(C.byref(self.params), C.byref(h))
+        if st != capi.OK:
+            raise capi.RvsegError(st, capi.lib().rvseg_last_error(None).decode("utf-8", "replace"))
+        self.h = h
+        self.L = capi.lib()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rvseg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- forest ------------------------------------------------------------------------------
+    @property
+    def feature_length(self):
+        return self.L.rvseg_feature_length(self.h)
+
+    def forest_load(self, src):
+        if isinstance(src, (bytes, bytearray, memoryview)):
+            buf = bytes(src)
+            capi.check(self.h, self.L.rvseg_forest_load_mem(self.h, buf, len(buf)))
+        else:
+            capi.check(self.h, self.L.rvseg_forest_load(self.h, str(src).encode()))
+
+    def forest_info(self):
+        nt, nn, md, nl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        cc = (C.c_int32 * capi.RVSEG_MAX_LAYERS)()
+        capi.check(self.h, self.L.rvseg_forest_info(self.h, C.byref(nt), C.byref(nn), C.byref(md), C.byref(nl), C.byref(cc)))
+        return {"n_trees": nt.value, "n_nodes": nn.value, "max_depth": md.value,
+                "class_counts": [cc[i] for i in range(nl.value)]}
+
+    def forest_eval(self, X):
+        X = np.ascontiguousarray(X, np.float32)
+        P, D = X.shape
+        S = sum(self.forest_info()["class_counts"])
+        out = np.empty((P, S), np.float32)
+        capi.check(self.h, self.L.rvseg_forest_eval(self.h, _ptr(X), P, D, _ptr(out)))
+        return out
+
+    # ---- features ----------------------------------------------------------------------------
+    def extract_features(self, rgb, depth, calib):
+        p = self.params
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        calib = np.ascontiguousarray(calib, np.float32)
+        assert rgb.shape == (p.height, p.width, 3) and depth.shape == (p.height, p.width) and calib.size == 21
+        cap = (p.height // p.stride + 1) * (p.width // p.stride + 1)
+        D = self.feature_length
+        feat = np.empty((cap, D), np.float32)
+        xv = np.empty(cap, np.int32)
+        yv = np.empty(cap, np.int32)
+        n = C.c_int32()
+        capi.check(self.h, self.L.rvseg_extract_features(self.h, _ptr(rgb), _ptr(depth), _ptr(calib), _ptr(feat), _ptr(xv), _ptr(yv), C.byref(n)))
+        return feat[:n.value].copy(), xv[:n.value].copy(), yv[:n.value].copy()
+
+    # ---- whole path --------------------------------------------------------------------------
+    def segment_frames(self, rgb, depth, calib, want_posteriors=True, want_marginals=None, want_labels=True):
+        p = self.params
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        n = rgb.shape[0]
+        assert rgb.shape == (n, p.height, p.width, 3) and depth.shape == (n, p.height, p.width)
+        calib = np.ascontiguousarray(np.broadcast_to(np.asarray(calib, np.float32).reshape(-1, 21), (n, 21)))
+        cc = self.forest_info()["class_counts"]
+        S, Lc, N = sum(cc), len(cc), p.width * p.height
+        if want_marginals is None:
+            want_marginals = bool(p.use_dense_crf)
+        post = np.empty((n, S * N), np.float32) if want_posteriors else None
+        marg = np.empty((n, S * N), np.float32) if want_marginals else None
+        lab = np.empty((n, Lc, p.height, p.width), np.int8) if want_labels else None
+        capi.check(self.h, self.L.rvseg_segment_frames(self.h, n, _ptr(rgb), _ptr(depth), _ptr(calib), _ptr(post), _ptr(marg), _ptr(lab)))
+        return {"posteriors": post, "marginals": marg, "labels": lab, "class_counts": cc}
+
+    def segment_frames_device(self, n, d_rgb, d_depth, calib, d_post=0, d_marg=0, d_labels=0, stream=0):
+        """Device-pointer variant: integer addresses (e.g. torch tensor.data_ptr()) and a raw
+        hipStream_t handle.  Enqueues only; the caller synchronises."""
+        calib = np.ascontiguousarray(np.broadcast_to(np.asarray(calib, np.float32).reshape(-1, 21), (n, 21)))
+        capi.check(self.h, self.L.rvseg_segment_frames_device(
+            self.h, n, C.c_void_p(d_rgb), C.c_void_p(d_depth), _ptr(calib),
+            C.c_void_p(d_post or None), C.c_void_p(d_marg or None), C.c_void_p(d_labels or None),
+            C.c_void_p(stream or None)))
+
+    # ---- CRF ---------------------------------------------------------------------------------
+    def crf_infer(self, unary_energy, features, potts_w, iterations, label_mode=capi.LABEL_ARGMAX, unknown_label=0):
+        U = np.ascontiguousarray(unary_energy, np.float32)
+        F = np.ascontiguousarray(features, np.float32)
+        N, Cn = U.shape
+        assert F.shape[0] == N
+        Q = np.empty_like(U)
+        mp = np.empty(N, np.int8)
+        capi.check(self.h, self.L.rvseg_crf_infer(self.h, N, Cn, F.shape[1], _ptr(U), _ptr(F), C.c_float(potts_w), iterations, _ptr(Q), _ptr(mp), label_mode, unknown_label))
+        return Q, mp
+
+    def crf_infer_multi(self, unary_energy, features, ws, iterations, label_mode=capi.LABEL_ARGMAX, unknown_label=0):
+        U = np.ascontiguousarray(unary_energy, np.float32)
+        N, Cn = U.shape
+        feats = [np.ascontiguousarray(f, np.float32) for f in features]
+        ds = (C.c_int32 * len(feats))(*[f.shape[1] for f in feats])
+        ptrs = (C.c_void_p * len(feats))(*[f.ctypes.data for f in feats])
+        wsa = (C.c_float * len(feats))(*ws)
+        Q = np.empty_like(U)
+        mp = np.empty(N, np.int8)
+        capi.check(self.h, self.L.rvseg_crf_infer_multi(self.h, N, Cn, len(feats), ds, ptrs, wsa, _ptr(U), iterations, _ptr(Q), _ptr(mp), label_mode, unknown_label))
+        return Q, mp
+
+    def lattice_build(self, features, keys_capacity=None):
+        F = np.ascontiguousarray(features, np.float32)
+        N, d = F.shape
+        cap = keys_capacity or N * (d + 1) + 8 * (d + 1)
+        off = np.empty((N, d + 1), np.int32)
+        bary = np.empty((N, d + 1), np.float32)
+        keys = np.empty((cap, d), np.int16)
+        M = C.c_int32()
+        capi.check(self.h, self.L.rvseg_lattice_build(self.h, _ptr(F), N, d, _ptr(off), _ptr(bary), _ptr(keys), cap, C.byref(M)))
+        return off, bary, keys[:M.value].copy(), M.value
+
+    def lattice_filter(self, values):
+        V = np.ascontiguousarray(values, np.float32)
+        out = np.empty_like(V)
+        capi.check(self.h, self.L.rvseg_lattice_filter(self.h, _ptr(V), V.shape[1], _ptr(out)))
+        return out
+
+    def last_timing(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        n = self.L.rvseg_last_timing(self.h, names, 4096, ms, 64)
+        ns = names.value.decode().split(";") if names.value else []
+        return {ns[i]: ms[i] for i in range(min(n, len(ns)))}
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-shaped facades
+# ---------------------------------------------------------------------------------------------
+class RandomForest:
+    """libf::RandomForest as the hot path uses it (classifiers.h:274-344)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def read(self, src):  # RandomForest::read(std::istream&), classifier.cpp:222
+        self.ctx.forest_load(src)
+
+    def getSize(self):
+        return self.ctx.forest_info()["n_trees"]
+
+    def classLogPosterior(self, X):  # classifier.cpp:166 -- ctx must have multi_layer=0
+        return self.ctx.forest_eval(np.atleast_2d(X))
+
+    def multiClassLogPosterior(self, X):  # classifier.cpp:187 -- ctx must have multi_layer=1
+        out = self.ctx.forest_eval(np.atleast_2d(X))
+        cc = self.ctx.forest_info()["class_counts"]
+        offs = np.cumsum([0] + cc)
+        return [out[:, offs[i]:offs[i + 1]] for i in range(len(cc))]
+
+
+class FeatureExtractor:
+    """Features::FeatureExtractor (include/feature_extractor.h:24-41), NO_LABEL extraction."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def extract(self, color, depth, calib):
+        return self.ctx.extract_features(color, depth, calib)
+
+
+class DenseCRF:
+    """DenseCRF as Segmenter::processMapFromQueue drives it (src/segmenter.cpp:641-644)."""
+
+    def __init__(self, ctx, N, M):
+        self.ctx, self.N, self.M = ctx, N, M
+        self.unary = None
+        self.kernels = []
+
+    def setUnaryEnergy(self, unary):  # densecrf.cpp:89-91; unary is N x M energy (= -log-posterior)
+        unary = np.ascontiguousarray(unary, np.float32)
+        assert unary.shape == (self.N, self.M)
+        self.unary = unary
+
+    def addPairwiseEnergy(self, features, potts_weight):  # densecrf.cpp:54-60 + PottsCompatibility
+        features = np.ascontiguousarray(features, np.float32)
+        assert features.shape[0] == self.N  # assert(features.cols() == N_), densecrf.cpp:55
+        self.kernels.append((features, float(potts_weight)))
+
+    def addPairwiseGaussian(self, W, H, sx, sy, w):  # densecrf.cpp:61-69
+        ys, xs = np.mgrid[0:H, 0:W]
+        f = np.stack([xs.ravel().astype(np.float32) / np.float32(sx), ys.ravel().astype(np.float32) / np.float32(sy)], 1)
+        self.addPairwiseEnergy(f, w)
+
+    def addPairwiseBilateral(self, W, H, sx, sy, sr, sg, sb, im, w):  # densecrf.cpp:70-81
+        ys, xs = np.mgrid[0:H, 0:W]
+        im = np.asarray(im, np.uint8).reshape(H * W, 3).astype(np.float32)
+        f = np.stack([xs.ravel().astype(np.float32) / np.float32(sx), ys.ravel().astype(np.float32) / np.float32(sy),
+                      im[:, 0] / np.float32(sr), im[:, 1] / np.float32(sg), im[:, 2] / np.float32(sb)], 1)
+        self.addPairwiseEnergy(f, w)
+
+    def inference(self, n_iterations, label_mode=capi.LABEL_ARGMAX, unknown_label=0):  # densecrf.cpp:115-131
+        U = self.unary if self.unary is not None else np.zeros((self.N, self.M), np.float32)
+        if len(self.kernels) == 1:
+            f, w = self.kernels[0]
+            return self.ctx.crf_infer(U, f, w, n_iterations, label_mode, unknown_label)
+        return self.ctx.crf_infer_multi(U, [k[0] for k in self.kernels], [k[1] for k in self.kernels], n_iterations, label_mode, unknown_label)
+
+    def map(self, n_iterations):  # densecrf.cpp:132-137
+        return self.inference(n_iterations, capi.LABEL_ARGMAX)[1]
+
+
+class Segmenter:
+    """The per-frame inference part of `class Segmenter` (include/segmenter.h:47-69), ROS-free:
+    construction loads the forest like Segmenter::Segmenter (src/segmenter.cpp:106-129),
+    processFrames does what processFramesFromQueueInternalRF does per dequeued frame
+    (src/segmenter.cpp:351-431) for a whole batch, plus the per-frame DenseCRF when enabled."""
+
+    def __init__(self, forest, **params):
+        self.ctx = Context(**params)
+        self.ctx.forest_load(forest)
+        info = self.ctx.forest_info()
+        self.layer_class_counts = info["class_counts"]
+        self.layer_count = len(self.layer_class_counts)
+
+    def processFrames(self, color, depth, calib, **kw):
+        return self.ctx.segment_frames(color, depth, calib, **kw)
+
+    def close(self):
+        self.ctx.close()
