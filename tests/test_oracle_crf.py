@@ -1,0 +1,242 @@
+"""Property and known-answer tests of the oracle's permutohedral lattice and DenseCRF (rows N-W).
+
+PARITY UNPINNED at the reference level: permutohedral.cpp cannot be compiled here (it needs Eigen,
+which is absent, and no stand-in header may be written) and the reference ships no vectors for
+it.  These tests pin the restatement by mathematics instead: barycentric interpolation identity,
+Gaussian-filter approximation, transpose symmetry, softmax identities, and the dense_inference
+example recipe on the reference's own PPM inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+
+
+def _elevate(f):
+    """E*p of Adams et al. 2010 in float64, with the scale of permutohedral.cpp:177-182."""
+    d = f.shape[1]
+    inv_std = np.sqrt(2.0 / 3.0) * (d + 1)
+    sf = np.array([1.0 / np.sqrt((i + 2) * (i + 1)) * inv_std for i in range(d)])
+    cf = f * sf
+    el = np.zeros((f.shape[0], d + 1))
+    sm = np.zeros(f.shape[0])
+    for j in range(d, 0, -1):
+        el[:, j] = sm - j * cf[:, j - 1]
+        sm = sm + cf[:, j - 1]
+    el[:, 0] = sm
+    return el
+
+
+def test_lattice_d1_known_answer(oracle):
+    # f = 0 sits exactly on a lattice vertex: weights (1, 0), vertices with keys 0 and 1
+    lat = oracle.Lattice(np.zeros((4, 1), np.float32))
+    assert lat.M == 2
+    assert np.array_equal(lat.barycentric[0], np.array([1.0, 0.0], np.float32))
+    assert lat.keys[lat.offset[0, 0]].tolist() == [0] and lat.keys[lat.offset[0, 1]].tolist() == [1]
+    # d = 1: elevated = (cf, -cf), cf = f*2/sqrt(3); lattice vertices are (k,-k).
+    # f = sqrt(3)/4 -> elevated (.5,-.5): midpoint between vertices (0,0) and (1,-1)
+    f = np.full((4, 1), np.sqrt(3) / 4, np.float32)
+    lat = oracle.Lattice(f)
+    assert np.allclose(lat.barycentric[0], [0.5, 0.5], atol=1e-6)
+    assert sorted(lat.keys[lat.offset[0]].ravel().tolist()) == [0, 1]
+    # f = sqrt(3)/2 -> elevated (1,-1): exactly on vertex 1
+    lat = oracle.Lattice(np.full((4, 1), np.sqrt(3) / 2, np.float32))
+    w = dict(zip(lat.keys[lat.offset[0]].ravel().tolist(), lat.barycentric[0].tolist()))
+    assert abs(w[1] - 1) < 1e-6
+
+
+@pytest.mark.parametrize("d", [2, 5, 6])
+def test_barycentric_interpolation_identity(oracle, d):
+    rng = np.random.default_rng(d)
+    N = 2000
+    f = (rng.random((N, d)) * 6 - 3).astype(np.float32)
+    lat = oracle.Lattice(f)
+    b = lat.barycentric.astype(np.float64)
+    assert np.allclose(b.sum(1), 1.0, atol=1e-5)
+    assert b.min() > -1e-5
+    assert lat.offset.min() >= 0 and lat.offset.max() < lat.M
+    # each point's d+1 vertices are distinct
+    assert all(len(set(r)) == d + 1 for r in lat.offset[:200].tolist())
+    # sum_r b_r * vertex_r == elevated point (first d coordinates)
+    el = _elevate(f.astype(np.float64))
+    verts = lat.keys[lat.offset].astype(np.float64)  # N x (d+1) x d
+    recon = (b[:, :, None] * verts).sum(1)
+    assert np.abs(recon - el[:, :d]).max() < 2e-4
+    # keys are unique
+    assert len({tuple(k) for k in lat.keys.tolist()}) == lat.M
+
+
+def test_blur_neighbours_are_lattice_neighbours(oracle):
+    rng = np.random.default_rng(0)
+    d = 3
+    f = (rng.random((500, d)) * 4).astype(np.float32)
+    lat = oracle.Lattice(f)
+    index = {tuple(k): i for i, k in enumerate(lat.keys.tolist())}
+    for j in range(d + 1):
+        for i in range(0, lat.M, 7):
+            k = lat.keys[i].astype(int)
+            n1, n2 = k - 1, k + 1
+            if j < d:
+                n1[j] = k[j] + d
+                n2[j] = k[j] - d
+            assert lat.blur_n1[j, i] == index.get(tuple(n1), -1)
+            assert lat.blur_n2[j, i] == index.get(tuple(n2), -1)
+
+
+def test_filter_approximates_gaussian(oracle):
+    rng = np.random.default_rng(1)
+    N, d = 1500, 2
+    f = (rng.random((N, d)) * 5).astype(np.float32)
+    v = rng.random((N, 3)).astype(np.float32)
+    lat = oracle.Lattice(f)
+    got = lat.compute(v).astype(np.float64)
+    D2 = ((f[:, None, :].astype(np.float64) - f[None, :, :]) ** 2).sum(-1)
+    want = np.exp(-0.5 * D2) @ v.astype(np.float64)
+    ratio = got / want
+    assert 0.85 < np.median(ratio) < 1.15
+    assert np.corrcoef(got.ravel(), want.ravel())[0, 1] > 0.98
+
+
+def test_reverse_is_transpose_and_seq_matches_sse(oracle):
+    rng = np.random.default_rng(2)
+    N, d = 800, 4
+    f = (rng.random((N, d)) * 3).astype(np.float32)
+    lat = oracle.Lattice(f)
+    a = rng.random((N, 3)).astype(np.float32)
+    b = rng.random((N, 3)).astype(np.float32)
+    lhs = (a.astype(np.float64) * lat.compute(b)).sum()
+    rhs = (lat.compute(a, reverse=True).astype(np.float64) * b).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-5
+    s = lat.compute(a, which="seq")
+    e = lat.compute(a, which="sse")
+    assert np.allclose(s, e, rtol=2e-6, atol=1e-7)
+    # dispatch rule of Permutohedral::compute (permutohedral.cpp:600-603)
+    assert np.array_equal(lat.compute(a[:, :2]), lat.compute(a[:, :2], which="seq"))
+    assert np.array_equal(lat.compute(a), lat.compute(a, which="sse"))
+
+
+def test_padding_lanes_are_inserted(oracle):
+    # N not a multiple of 4: the padded all-zero lanes add the zero point's vertices
+    # (permutohedral.cpp:196,261-275)
+    f = np.full((5, 2), 7.3, np.float32)
+    lat5 = oracle.Lattice(f)
+    lat8 = oracle.Lattice(np.full((8, 2), 7.3, np.float32))
+    assert lat8.M == 3 and lat5.M == 6
+    assert [0, 0] in lat5.keys.tolist()
+
+
+def test_exp_close_to_libm(oracle):
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([-rng.random(3000) * 30, [0.0, -1e-8, -87.0, -100.0, -103.9, -104.5, -1000.0]]).astype(np.float32)
+    bad = 0
+    for x in xs:
+        got = np.float32(oracle.exp_f32(x))
+        want = np.float32(np.exp(np.float64(x)))
+        if got != want:
+            bad += 1
+            assert abs(float(got) - float(want)) <= np.spacing(max(want, np.float32(1e-45)))
+    assert bad <= 3
+    assert oracle.exp_f32(0.0) == 1.0 and oracle.exp_f32(-1000.0) == 0.0
+
+
+def test_exp_and_normalize(oracle):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((500, 9)) * 5).astype(np.float32)
+    q = oracle.exp_and_normalize(x)
+    x64 = x.astype(np.float64)
+    ref = np.exp(x64 - x64.max(1, keepdims=True))
+    ref /= ref.sum(1, keepdims=True)
+    assert np.abs(q - ref).max() < 3e-7
+    assert np.allclose(q.sum(1), 1, atol=1e-6)
+
+
+def test_inference_without_pairwise_weight_is_softmax(oracle):
+    rng = np.random.default_rng(5)
+    N, C = 400, 5
+    U = (rng.random((N, C)) * 4).astype(np.float32)
+    F = rng.random((N, 3)).astype(np.float32)
+    Q = oracle.crf_inference(U, F, 0.0, 3)
+    assert np.array_equal(Q, oracle.exp_and_normalize(-U))
+
+
+def test_inference_smooths_towards_neighbours(oracle):
+    # two clusters in feature space; one outlier pixel inside cluster A votes for class 1 weakly
+    N, C = 64, 2
+    F = np.zeros((N, 2), np.float32)
+    F[32:] = 50.0
+    U = np.zeros((N, C), np.float32)
+    U[:32, 1] = 2.0          # cluster A prefers class 0
+    U[32:, 0] = 2.0          # cluster B prefers class 1
+    U[5] = (0.3, 0.0)        # outlier in A weakly prefers class 1
+    Q0 = oracle.crf_inference(U, F, 0.0, 1)
+    Q5 = oracle.crf_inference(U, F, 5.0, 5)
+    assert Q0[5, 1] > 0.5 and Q5[5, 0] > 0.9
+    assert (Q5[32:, 1] > 0.9).all() and (Q5[:32, 0] > 0.9).all()
+
+
+def read_ppm(path):
+    with open(path, "rb") as fh:
+        data = fh.read()
+    toks, pos = [], 0
+    while len(toks) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        toks.append(data[pos:end])
+        pos = end
+    assert toks[0] == b"P6"
+    W, H = int(toks[1]), int(toks[2])
+    return np.frombuffer(data, np.uint8, W * H * 3, pos + 1).reshape(H, W, 3)
+
+
+def dense_inference_inputs(golden_dir, M=21, GT_PROB=0.5):
+    """Unary of examples/dense_inference.cpp:37-52 and labelling of examples/common.cpp:49-66."""
+    im = read_ppm(os.path.join(golden_dir, "im2.ppm"))
+    anno = read_ppm(os.path.join(golden_dir, "anno2.ppm"))
+    H, W, _ = im.shape
+    a64 = anno.astype(np.int64)
+    col = a64[..., 0] + 256 * a64[..., 1] + 65536 * a64[..., 2]
+    colors, lbl = [], np.empty(H * W, np.int64)
+    for k, c in enumerate(col.ravel().tolist()):
+        if c and c not in colors and len(colors) < M:
+            colors.append(c)
+        lbl[k] = colors.index(c) if (c and c in colors) else -1
+    u_energy = np.float32(-np.log(1.0 / M))
+    n_energy = np.float32(-np.log((1.0 - GT_PROB) / (M - 1)))
+    p_energy = np.float32(-np.log(GT_PROB))
+    U = np.full((H * W, M), u_energy, np.float32)
+    lab = lbl >= 0
+    U[lab] = n_energy
+    U[np.nonzero(lab)[0], lbl[lab]] = p_energy
+    return im, lbl, U, W, H
+
+
+def test_dense_inference_example_recipe(oracle, golden_dir):
+    im, lbl, U, W, H = dense_inference_inputs(golden_dir)
+    ys, xs = np.mgrid[0:H, 0:W]
+    x, y = xs.ravel().astype(np.float32), ys.ravel().astype(np.float32)
+    g = np.stack([x / np.float32(3), y / np.float32(3)], 1)
+    imf = im.reshape(-1, 3).astype(np.float32)
+    b = np.stack([x / np.float32(80), y / np.float32(80), imf[:, 0] / np.float32(13), imf[:, 1] / np.float32(13), imf[:, 2] / np.float32(13)], 1)
+    Q = oracle.crf_inference_multi(U, [g, b], [3.0, 10.0], 5)
+    assert np.allclose(Q.sum(1), 1, atol=1e-5)
+    mp = Q.argmax(1)
+    n_lab = lbl.max() + 1
+    assert set(np.unique(mp).tolist()) <= set(range(n_lab))
+    # annotated pixels overwhelmingly keep their scribble label; the map is much smoother than the
+    # unary argmax (which is arbitrary on unannotated pixels)
+    keep = (mp[lbl >= 0] == lbl[lbl >= 0]).mean()
+    assert keep > 0.8
+    trans = (mp.reshape(H, W)[:, 1:] != mp.reshape(H, W)[:, :-1]).mean()
+    assert trans < 0.06
+    # regression vector (generated by this oracle, NOT by the reference): guards against drift
+    path = os.path.join(golden_dir, "crf_im2_regression.npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        assert np.array_equal(mp.astype(np.int8), z["map"])
+        assert np.array_equal(Q[::97], z["q_sub"])
