@@ -1,0 +1,72 @@
+// Deterministic elementary functions for the device.  Each is a fixed sequence of IEEE double
+// +,-,*,/,sqrt,rint, compiled with -ffp-contract=off, so that it rounds identically on gfx950 and
+// on the x86 host that runs the CPU oracle (which states the same sequences independently in
+// oracle/rvseg_oracle.c).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rvseg {
+
+// fdlibm acos for x in [0,1], narrowed to float.  Replaces libm acos at
+// include/feature_extractor.h:283 of the reference.
+__device__ __forceinline__ float acos_f32_dev(float xf) {
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+                 pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+                 pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+                 pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+                 qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+                 qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+    double x = (double)xf;
+    if (x != x) return xf;
+    if (x >= 1.0) return 0.0f;
+    if (x < 0.0) x = 0.0;
+    if (x < 0.5) {
+        const double z = x * x;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = p / q;
+        return (float)(pio2_hi - (x - (pio2_lo - x * r)));
+    }
+    const double z = (1.0 - x) * 0.5;
+    const double s = sqrt(z);
+    const double df = __longlong_as_double(__double_as_longlong(s) & 0xFFFFFFFF00000000ll);
+    const double c = (z - df * df) / (s + df);
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double r = p / q;
+    const double w = r * s + c;
+    return (float)(2.0 * (df + w));
+}
+
+// exp for expAndNormalize (third-party/densecrf/src/densecrf.cpp:102): n = rint(x*log2e),
+// two-part ln2 reduction, degree-13 Taylor polynomial in Horner form, exact 2^n scaling.
+__device__ __forceinline__ float exp_f32_dev(float xf) {
+    double x = (double)xf;
+    if (x != x) return xf;
+    if (x < -104.0) return 0.0f;
+    if (x > 88.8) return __int_as_float(0x7f800000);
+    const double n = rint(x * 1.4426950408889634074);
+    const double r = (x - n * 6.93147180369123816490e-01) - n * 1.90821492927058770002e-10;
+    double p = 0x1.6124613a86d09p-33;
+    p = p * r + 0x1.1eed8eff8d898p-29;
+    p = p * r + 0x1.ae64567f544e4p-26;
+    p = p * r + 0x1.27e4fb7789f5cp-22;
+    p = p * r + 0x1.71de3a556c734p-19;
+    p = p * r + 0x1.a01a01a01a01ap-16;
+    p = p * r + 0x1.a01a01a01a01ap-13;
+    p = p * r + 0x1.6c16c16c16c17p-10;
+    p = p * r + 0x1.1111111111111p-7;
+    p = p * r + 0x1.5555555555555p-5;
+    p = p * r + 0x1.5555555555555p-3;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const double scale = __longlong_as_double(((long long)n + 1023) << 52);
+    return (float)(p * scale);
+}
+
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+
+}  // namespace rvseg

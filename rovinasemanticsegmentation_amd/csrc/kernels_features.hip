@@ -1,0 +1,271 @@
+// Feature-side kernels for gfx950: Lab conversion + back-projection, the PCL-style smoothing-window
+// map (depth-change map + two-pass chamfer distance), and the normal feature.
+//
+// Reference: include/feature_extractor.h:125-291.  The arithmetic of cvtColor / PCL normals lives
+// in libraries the reference does not vendor; the definitions implemented here are the ones
+// written down in DESIGN.md and restated independently by the CPU oracle.
+#include "device_math.h"
+#include "rvseg_internal.h"
+#include "rvseg_kernels.h"
+
+namespace rvseg {
+
+// ---------------------------------------------------------------------------------------------
+// prep: one thread per pixel.
+//   lab   : cvtColor(CV_BGR2Lab) on 8-bit data, integer LUT pipeline (feature_extractor.h:129),
+//           stored as one dword (L | a<<8 | b<<16) so that the patch kernel fetches a tap with a
+//           single load.
+//   cloud : (R*Kinv)*(d*x, d*y, d) + t, NaN where depth is outside [d_min, d_max]
+//           (feature_extractor.h:209-223), stored float4 (x,y,z,0).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ cbrt_tab,
+            const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth,
+            const float* __restrict__ calibA,  // n x 12: A = R*Kinv (row-major 9), t (3)
+            uint32_t* __restrict__ lab, float4* __restrict__ cloud, int n_frames) {
+    const size_t npix = (size_t)g.W * g.H;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * (size_t)n_frames) return;
+    const int frame = (int)(gid / npix);
+    const int pix = (int)(gid - (size_t)frame * npix);
+    const int y = pix / g.W, x = pix - y * g.W;
+
+    if (lab) {
+        const uint8_t* s = rgb + gid * 3;
+        const int c0 = gamma[s[0]], c1 = gamma[s[1]], c2 = gamma[s[2]];
+        const int fX = cbrt_tab[(c0 * lc.c[0] + c1 * lc.c[1] + c2 * lc.c[2] + (1 << 11)) >> 12];
+        const int fY = cbrt_tab[(c0 * lc.c[3] + c1 * lc.c[4] + c2 * lc.c[5] + (1 << 11)) >> 12];
+        const int fZ = cbrt_tab[(c0 * lc.c[6] + c1 * lc.c[7] + c2 * lc.c[8] + (1 << 11)) >> 12];
+        const int Lscale = (116 * 255 + 50) / 100;
+        const int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+        int L = (Lscale * fY + Lshift + (1 << 14)) >> 15;
+        int a = (500 * (fX - fY) + 128 * (1 << 15) + (1 << 14)) >> 15;
+        int b = (200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15;
+        L = min(max(L, 0), 255); a = min(max(a, 0), 255); b = min(max(b, 0), 255);
+        lab[gid] = (uint32_t)L | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+    }
+    if (cloud) {
+        const float* A = calibA + (size_t)frame * 12;
+        const float d = (float)depth[gid] / 1000.0f;
+        float m0, m1, m2;
+        if (d < g.depth_min || d > g.depth_max) {
+            m0 = m1 = m2 = __int_as_float(0x7fc00000);
+        } else {
+            m0 = d * (float)x; m1 = d * (float)y; m2 = d;
+        }
+        float4 o;
+        o.x = ((A[0] * m0 + A[1] * m1) + A[2] * m2) + A[9];
+        o.y = ((A[3] * m0 + A[4] * m1) + A[5] * m2) + A[10];
+        o.z = ((A[6] * m0 + A[7] * m1) + A[8] * m2) + A[11];
+        o.w = 0.f;
+        cloud[gid] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothing-window map.  PCL computes a depth-change map, then a two-pass raster chamfer distance
+// (steps 1.0 / 1.4 in float), then window = int(min(distance, 10)) (NaN normal when <= 2).
+// The raster passes are sequential over the whole image; only distances below 10 matter and every
+// step costs >= 1, so a pixel's value is decided inside its 21x21 neighbourhood.  Each workgroup
+// (one wave) therefore re-runs both raster passes on its tile plus a 20-pixel apron held in LDS,
+// sweeping anti-diagonals t = 2*row + col so that all four already-final neighbours of a cell
+// are available.  The float additions follow the raster order exactly, so the result equals the
+// sequential algorithm wherever it is below 10 (and is >= 10 wherever that is).
+// ---------------------------------------------------------------------------------------------
+constexpr int DM_TW = 64, DM_TH = 16, DM_APRON = 20;
+constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 104
+constexpr int DM_CH = DM_TH + 2 * DM_APRON;  // 56
+
+__device__ __forceinline__ float cloud_z(const float4* __restrict__ cloud, int W, int r, int c) {
+    return cloud[(size_t)r * W + c].z;
+}
+
+__device__ __forceinline__ bool pair_fails(float z0, float z1) {
+    const float thr = (0.02f * (fabsf(z0) + 1.0f) * 2.0f);
+    return fabsf(z0 - z1) > thr || !finite_f(z0) || !finite_f(z1);
+}
+
+__global__ void __launch_bounds__(64)
+window_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __restrict__ rect_all) {
+    __shared__ float dist[DM_CH * DM_CW];
+    __shared__ int any_zero;
+    const int W = g.W, H = g.H;
+    const int tiles_x = (W + DM_TW - 1) / DM_TW;
+    const int tiles_y = (H + DM_TH - 1) / DM_TH;
+    const int frame = blockIdx.x / (tiles_x * tiles_y);
+    const int tile = blockIdx.x - frame * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x0 = tx * DM_TW - DM_APRON, y0 = ty * DM_TH - DM_APRON;
+    const float4* cloud = cloud_all + (size_t)frame * W * H;
+    uint8_t* rect = rect_all + (size_t)frame * W * H;
+    const int lane = threadIdx.x;
+    const float BIG = (float)(W + H);
+
+    if (lane == 0) any_zero = 0;
+    __syncthreads();
+    int my_zero = 0;
+    for (int idx = lane; idx < DM_CH * DM_CW; idx += 64) {
+        const int lr = idx / DM_CW, lc = idx - lr * DM_CW;
+        const int r = y0 + lr, c = x0 + lc;
+        float v = BIG;
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            const float z = cloud_z(cloud, W, r, c);
+            bool change = false;
+            if (r <= H - 2 && c <= W - 2)
+                change = pair_fails(z, cloud_z(cloud, W, r, c + 1)) || pair_fails(z, cloud_z(cloud, W, r + 1, c));
+            if (!change && c >= 1 && r <= H - 2) change = pair_fails(cloud_z(cloud, W, r, c - 1), z);
+            if (!change && r >= 1 && c <= W - 2) change = pair_fails(cloud_z(cloud, W, r - 1, c), z);
+            if (change) { v = 0.0f; my_zero = 1; }
+        }
+        dist[idx] = v;
+    }
+    if (my_zero) any_zero = 1;
+    __syncthreads();
+
+    if (any_zero) {
+        // first pass: rows 1..H-1, columns 1..W-1 of the image, raster order
+        const int n_steps = 2 * (DM_CH - 1) + DM_CW;
+        for (int t = 0; t < n_steps; t++) {
+            const int lr = lane, lc = t - 2 * lane;
+            if (lr < DM_CH && lc >= 0 && lc < DM_CW) {
+                const int r = y0 + lr, c = x0 + lc;
+                if (r >= 1 && r < H && c >= 1 && c < W) {
+                    const float* cur = dist + lr * DM_CW;
+                    const bool has_prev = lr >= 1;
+                    const float* prev = cur - DM_CW;
+                    const float upLeft = (has_prev && lc >= 1 ? prev[lc - 1] : BIG) + 1.4f;
+                    const float up = (has_prev ? prev[lc] : BIG) + 1.0f;
+                    const float upRight = (has_prev && lc + 1 < DM_CW && c + 1 < W ? prev[lc + 1] : BIG) + 1.4f;
+                    const float left = (lc >= 1 ? cur[lc - 1] : BIG) + 1.0f;
+                    const float center = cur[lc];
+                    const float mn = fminf(fminf(upLeft, up), fminf(left, upRight));
+                    if (mn < center) dist[lr * DM_CW + lc] = mn;
+                }
+            }
+            __syncthreads();
+        }
+        // second pass: rows H-2..0, columns W-2..0, reverse raster order
+        for (int t = 0; t < n_steps; t++) {
+            const int lr = DM_CH - 1 - lane, lc = DM_CW - 1 - (t - 2 * lane);
+            if (lr >= 0 && lc >= 0 && lc < DM_CW && (t - 2 * lane) >= 0) {
+                const int r = y0 + lr, c = x0 + lc;
+                if (r >= 0 && r <= H - 2 && c >= 0 && c <= W - 2) {
+                    const float* cur = dist + lr * DM_CW;
+                    const bool has_next = lr + 1 < DM_CH;
+                    const float* next = cur + DM_CW;
+                    const float lowerLeft = (has_next && lc >= 1 && c >= 1 ? next[lc - 1] : BIG) + 1.4f;
+                    const float lower = (has_next ? next[lc] : BIG) + 1.0f;
+                    const float lowerRight = (has_next && lc + 1 < DM_CW ? next[lc + 1] : BIG) + 1.4f;
+                    const float right = (lc + 1 < DM_CW ? cur[lc + 1] : BIG) + 1.0f;
+                    const float center = cur[lc];
+                    const float mn = fminf(fminf(lowerLeft, lower), fminf(right, lowerRight));
+                    if (mn < center) dist[lr * DM_CW + lc] = mn;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // window size per pixel of the tile: 0 <=> NaN normal (smoothing <= 2), else int(smoothing)
+    for (int idx = lane; idx < DM_TH * DM_TW; idx += 64) {
+        const int lr = idx / DM_TW + DM_APRON, lc = idx % DM_TW + DM_APRON;
+        const int r = y0 + lr, c = x0 + lc;
+        if (r < H && c < W) {
+            const float dv = dist[lr * DM_CW + lc];
+            const float smoothing = dv < 10.0f ? dv : 10.0f;
+            rect[(size_t)r * W + c] = smoothing > 2.0f ? (uint8_t)(int)smoothing : (uint8_t)0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// normal feature at the stride-grid sample points: acos(|n_z|) or -2 (feature_extractor.h:275-283)
+// with n = normalise(sum_window(dy) x sum_window(dx)), gradients summed as 2^-32 fixed-point int64
+// (exact, order independent).  One thread per sample point.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long to_fix32(float v) {
+    double s = (double)v * 4294967296.0;
+    s = s > 9.0e18 ? 9.0e18 : s;
+    s = s < -9.0e18 ? -9.0e18 : s;
+    return __double2ll_rn(s);
+}
+
+__global__ void __launch_bounds__(256)
+normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const uint8_t* __restrict__ rect_all,
+                      float* __restrict__ nfeat_all, int n_frames) {
+    const int per_frame = g.lw * g.lh;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= per_frame * n_frames) return;
+    const int frame = gid / per_frame;
+    const int p = gid - frame * per_frame;
+    const int ly = p / g.lw, lx = p - ly * g.lw;
+    const int ri = ly * g.stride, ci = lx * g.stride;
+    const int W = g.W, H = g.H;
+    const float4* cloud = cloud_all + (size_t)frame * W * H;
+    const uint8_t* rect_map = rect_all + (size_t)frame * W * H;
+    float out = -2.0f;
+    const int border = 10;
+    if (ri >= border && ri < H - border && ci >= border && ci < W - border) {
+        const int rect = rect_map[(size_t)ri * W + ci];
+        const float zc = cloud[(size_t)ri * W + ci].z;
+        if (rect > 0 && finite_f(zc)) {
+            const int rect2 = rect >> 1;
+            const int sx = ci - rect2, sy = ri - rect2;
+            long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
+            int cnt_x = 0, cnt_y = 0;
+            for (int y = sy; y < sy + rect; y++) {
+                for (int x = sx; x < sx + rect; x++) {
+                    float dx0 = 0.f, dx1 = 0.f, dx2 = 0.f, dy0 = 0.f, dy1 = 0.f, dy2 = 0.f;
+                    if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+                        const float4 r = cloud[(size_t)y * W + x + 1], l = cloud[(size_t)y * W + x - 1];
+                        const float4 dn = cloud[(size_t)(y + 1) * W + x], up = cloud[(size_t)(y - 1) * W + x];
+                        dx0 = r.x - l.x; dx1 = r.y - l.y; dx2 = r.z - l.z;
+                        dy0 = dn.x - up.x; dy1 = dn.y - up.y; dy2 = dn.z - up.z;
+                    }
+                    if (finite_f(dx0) && finite_f(dx1) && finite_f(dx2)) {
+                        cnt_x++; gx0 += to_fix32(dx0); gx1 += to_fix32(dx1); gx2 += to_fix32(dx2);
+                    }
+                    if (finite_f(dy0) && finite_f(dy1) && finite_f(dy2)) {
+                        cnt_y++; gy0 += to_fix32(dy0); gy1 += to_fix32(dy1); gy2 += to_fix32(dy2);
+                    }
+                }
+            }
+            if (cnt_x > 0 && cnt_y > 0) {
+                const double k = 1.0 / 4294967296.0;
+                const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
+                const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
+                const double n0 = GY1 * GX2 - GY2 * GX1;
+                const double n1 = GY2 * GX0 - GY0 * GX2;
+                const double n2 = GY0 * GX1 - GY1 * GX0;
+                const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
+                if (len2 != 0.0) {
+                    const float nz = (float)(n2 / sqrt(len2));
+                    if (nz == nz) out = acos_f32_dev(fabsf(nz));
+                }
+            }
+        }
+    }
+    nfeat_all[gid] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
+                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, int n, hipStream_t s) {
+    LabCoeffs lc;
+    for (int i = 0; i < 9; i++) lc.c[i] = lab.coeffs[i];
+    const size_t total = (size_t)g.W * g.H * n;
+    prep_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+        g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, n);
+}
+
+void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_rect, int n, hipStream_t s) {
+    const int tiles = ((g.W + DM_TW - 1) / DM_TW) * ((g.H + DM_TH - 1) / DM_TH);
+    window_map_kernel<<<dim3((unsigned)(tiles * n)), dim3(64), 0, s>>>(g, d_cloud, d_rect);
+}
+
+void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
+                           int n, hipStream_t s) {
+    const int total = g.lw * g.lh * n;
+    normal_feature_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, d_cloud, d_rect, d_nfeat, n);
+}
+
+}  // namespace rvseg

@@ -8,6 +8,7 @@
 // dwordx4 load per visited node, the hot top levels of every tree packed at the front of each
 // tree's block so that they stay in L1/L2.
 #include "rvseg_internal.h"
+#include "rvseg_kernels.h"
 
 namespace rvseg {
 
@@ -87,6 +88,302 @@ void launch_forest_eval(const DeviceForest& f, const float* d_X, int P, int D, f
         forest_eval_kernel<4><<<dim3((unsigned)((threads + block - 1) / block)), dim3(block), 0, s>>>(
             nodes, roots, hist, f.n_trees, f.sum_classes, d_X, P, D, d_out);
     }
+}
+
+}  // namespace rvseg
+
+// =============================================================================================
+// Frame path: fused per-point feature vector + forest traversal over the stride grid
+// (replaces FeatureExtractor::extract + the per-point multiClassLogPosterior loop,
+// include/feature_extractor.h:125-197 and src/segmenter.cpp:351-376).
+//
+// A wavefront owns 16 consecutive sample points.  Their 363-byte Lab patch vectors are built
+// directly in LDS (the reference materialises P x 366 floats on the heap; here features never
+// touch HBM), then the 64 lanes become (point, tree) pairs and walk the breadth-first node array,
+// fetching one 16-byte node per level from HBM/L2 and the tested feature byte from LDS.
+// =============================================================================================
+namespace rvseg {
+
+constexpr int PPW = 16;              // points per wave
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct ClassMap {
+    int S, n_layers;
+    int layer_base[64];  // offset (in floats) of the class's layer block inside a frame's low-res buffer
+    int layer_C[64];     // class count of that layer
+    int cl[64];          // class index inside the layer
+};
+
+__device__ __forceinline__ int reflect_idx(int p, int len) {  // BORDER_REFLECT: fedcba|abcdefgh|hgfedcb
+    return p < 0 ? -p - 1 : (p >= len ? 2 * len - p - 1 : p);
+}
+
+template <bool DUMP>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes, const int32_t* __restrict__ roots,
+                 const float* __restrict__ hist, int n_trees, const ResizeRow* __restrict__ rt,
+                 const uint32_t* __restrict__ lab_all, const uint16_t* __restrict__ depth_all,
+                 const float4* __restrict__ cloud_all, const float* __restrict__ nfeat_all,
+                 float* __restrict__ low_all, float* __restrict__ dump_all, uint8_t* __restrict__ valid_all,
+                 int n_points_total, int fb_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // per wave: PPW x fb_stride bytes of patch features, then PPW x 8 ints of per-point state
+    unsigned char* fb = smem + (size_t)wave * (PPW * fb_stride + PPW * 32);
+    int* pst = reinterpret_cast<int*>(fb + PPW * fb_stride);  // [PPW][8]: valid,half,x,y,depth_f,height_f,normal_f,frame
+    const int per_frame = g.lw * g.lh;
+    const int base = (blockIdx.x * WAVES_PER_BLOCK + wave) * PPW;
+    const int W = g.W, H = g.H;
+
+    // ---- phase A: per-point state (mask rule feature_extractor.h:60; half size :139-140)
+    if (lane < PPW) {
+        const int pid = base + lane;
+        int valid = 0, half = 0, x = 0, y = 0, frame = 0;
+        float depth_m = 0.f, height = 0.f, nrm = 0.f;
+        if (pid < n_points_total) {
+            frame = pid / per_frame;
+            const int p = pid - frame * per_frame;
+            const int ly = p / g.lw, lx = p - ly * g.lw;
+            y = ly * g.stride; x = lx * g.stride;
+            const size_t pix = (size_t)frame * W * H + (size_t)y * W + x;
+            const uint16_t d = depth_all[pix];
+            const float dv = (float)d;
+            valid = (dv >= g.dmin_mm && dv <= g.dmax_mm) ? 1 : 0;
+            depth_m = dv / 1000.0f;
+            if (valid) {
+                half = (int)((double)g.patch_size / (2.0 * (double)depth_m));
+                if (g.pos_height >= 0) height = cloud_all[pix].z;
+                if (g.pos_normal >= 0) nrm = nfeat_all[pid];
+            }
+        }
+        int* s = pst + lane * 8;
+        s[0] = valid; s[1] = half; s[2] = x; s[3] = y;
+        s[4] = __float_as_int(depth_m); s[5] = __float_as_int(height); s[6] = __float_as_int(nrm); s[7] = frame;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+
+    // ---- phase B: Lab patch, cv::resize(ROI -> r x r) in 11-bit fixed point (feature_extractor.h:142)
+    if (g.n_patch > 0) {
+        const int rr = g.r * g.r;
+        for (int k0 = 0; k0 < rr; k0 += 64) {
+            const int k = k0 + lane;
+            const int dy = k / g.r, dx = k - dy * g.r;
+            for (int pt = 0; pt < PPW; pt++) {
+                const int* s = pst + pt * 8;
+                if (!s[0] || k >= rr) continue;
+                const int half = s[1], size = 2 * half + 1;
+                const int x0 = s[2] - half, y0 = s[3] - half;
+                const ResizeRow& row = rt[half];
+                const int sx0 = row.xofs[dx];
+                const int sx1 = sx0 + 1 < size ? sx0 + 1 : sx0;
+                int sy0 = row.yofs[dy], sy1 = sy0 + 1;
+                sy0 = sy0 < 0 ? 0 : (sy0 >= size ? size - 1 : sy0);
+                sy1 = sy1 < 0 ? 0 : (sy1 >= size ? size - 1 : sy1);
+                const int ia0 = row.ia0[dx], ia1 = row.ia1[dx], ib0 = row.ib0[dy], ib1 = row.ib1[dy];
+                const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
+                const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
+                const uint32_t* lab = lab_all + (size_t)s[7] * W * H;
+                const uint32_t p00 = lab[(size_t)ry0 * W + rx0], p01 = lab[(size_t)ry0 * W + rx1];
+                const uint32_t p10 = lab[(size_t)ry1 * W + rx0], p11 = lab[(size_t)ry1 * W + rx1];
+                unsigned char* dst = fb + pt * fb_stride + k * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const int sh = 8 * c;
+                    const int r0 = (int)((p00 >> sh) & 255u) * ia0 + (int)((p01 >> sh) & 255u) * ia1;
+                    const int r1 = (int)((p10 >> sh) & 255u) * ia0 + (int)((p11 >> sh) & 255u) * ia1;
+                    int v = (((ib0 * (r0 >> 4)) >> 16) + ((ib1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                    dst[c] = (unsigned char)v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (DUMP) {
+        for (int pt = 0; pt < PPW; pt++) {
+            const int pid = base + pt;
+            if (pid >= n_points_total) break;
+            const int* s = pst + pt * 8;
+            if (lane == 0) valid_all[pid] = (uint8_t)s[0];
+            float* d = dump_all + (size_t)pid * g.D;
+            for (int k = lane; k < g.n_patch; k += 64) d[k] = s[0] ? (float)fb[pt * fb_stride + k] : 0.f;
+            if (lane == 0) {
+                if (g.pos_depth >= 0) d[g.pos_depth] = __int_as_float(s[4]);
+                if (g.pos_height >= 0) d[g.pos_height] = __int_as_float(s[5]);
+                if (g.pos_normal >= 0) d[g.pos_normal] = __int_as_float(s[6]);
+            }
+        }
+        return;
+    }
+
+    // ---- phase C: lanes = (point, tree); findLeafNode (classifier.cpp:97-117)
+    const int pt = lane >> 2, sub = lane & 3;
+    const int* s = pst + pt * 8;
+    const bool valid = s[0] != 0;
+    const unsigned char* myfb = fb + pt * fb_stride;
+    int leaf_rows[16];
+    int n_mine = 0;
+    const int4* np = reinterpret_cast<const int4*>(nodes);
+    for (int t = sub; t < n_trees; t += 4) {
+        int row = 0;
+        if (valid) {
+            int4 nd = np[roots[t]];
+            while (nd.z != 0) {
+                const int f = nd.x;
+                float v;
+                if (f < g.n_patch) v = (float)myfb[f];
+                else v = __int_as_float(f == g.pos_depth ? s[4] : (f == g.pos_height ? s[5] : s[6]));
+                nd = np[(v < __int_as_float(nd.y)) ? nd.z : nd.z + 1];
+            }
+            row = nd.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) if (q == n_mine) leaf_rows[q] = row;
+        n_mine++;
+    }
+
+    // ---- phase D: tree-order accumulation (classifier.cpp:193-206) and scatter into the low-res
+    //      image at (y/stride, x/stride) (segmenter.cpp:369-375); invalid cells get the fill value
+    const int lane_base = lane & ~3;
+    const int pid = base + pt;
+    const int frame = s[7];
+    const int p = pid - frame * per_frame;
+    for (int c0 = 0; c0 < cm.S; c0 += 4) {
+        const int c = c0 + sub;
+        float acc = 0.f;
+        for (int t = 0; t < n_trees; t++) {
+            const int slot = t >> 2;
+            int row = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) if (q == slot) row = leaf_rows[q];
+            row = __shfl(row, lane_base + (t & 3), 64);
+            if (c < cm.S && valid) {
+                const float h = hist[(size_t)row * cm.S + c];
+                acc = (t == 0) ? h : acc + h;
+            }
+        }
+        if (pid < n_points_total && c < cm.S) {
+            float* low = low_all + (size_t)frame * per_frame * cm.S;
+            low[cm.layer_base[c] + (size_t)p * cm.layer_C[c] + cm.cl[c]] = valid ? acc : g.fill;
+        }
+    }
+}
+
+void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow* d_rt, const uint32_t* d_lab,
+                      const uint16_t* d_depth, const float4* d_cloud, const float* d_nfeat, float* d_low,
+                      float* d_dump, uint8_t* d_valid, int n, hipStream_t s) {
+    ClassMap cm{};
+    cm.S = f.sum_classes;
+    cm.n_layers = f.n_layers;
+    const int per_frame = g.lw * g.lh;
+    int c = 0, prefix = 0;
+    for (int l = 0; l < f.n_layers; l++) {
+        for (int k = 0; k < f.class_counts[l]; k++, c++) {
+            cm.layer_base[c] = per_frame * prefix;
+            cm.layer_C[c] = f.class_counts[l];
+            cm.cl[c] = k;
+        }
+        prefix += f.class_counts[l];
+    }
+    const int total = per_frame * n;
+    const int fb_stride = ((g.n_patch + 3) / 4) * 4 + 4;
+    const size_t smem = (size_t)WAVES_PER_BLOCK * (PPW * fb_stride + PPW * 32);
+    const int pts_per_block = PPW * WAVES_PER_BLOCK;
+    const dim3 grid((unsigned)((total + pts_per_block - 1) / pts_per_block)), block(64 * WAVES_PER_BLOCK);
+    if (d_dump)
+        rf_frames_kernel<true><<<grid, block, smem, s>>>(g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(),
+                                                         f.n_trees, d_rt, d_lab, d_depth, d_cloud, d_nfeat, d_low, d_dump, d_valid, total, fb_stride);
+    else
+        rf_frames_kernel<false><<<grid, block, smem, s>>>(g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(),
+                                                          f.n_trees, d_rt, d_lab, d_depth, d_cloud, d_nfeat, d_low, d_dump, d_valid, total, fb_stride);
+}
+
+// =============================================================================================
+// cv::resize(result, Size(W,H)) INTER_LINEAR on CV_32FC(C) + pack (segmenter.cpp:380-431).
+// One thread per output float so that stores are fully coalesced.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+upsample_pack_kernel(int W, int H, int lw, int lh, int C, size_t low_frame_stride, size_t low_layer_off,
+                     size_t post_frame_stride, size_t post_layer_off, const int* __restrict__ xofs,
+                     const float* __restrict__ ax0, const float* __restrict__ ax1, const int* __restrict__ yofs,
+                     const float* __restrict__ ay0, const float* __restrict__ ay1, const float* __restrict__ low_all,
+                     float* __restrict__ post_all, size_t total) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const size_t per_frame = (size_t)W * H * C;
+    const int frame = (int)(gid / per_frame);
+    const size_t e = gid - (size_t)frame * per_frame;
+    const int c = (int)(e % C);
+    const int pix = (int)(e / C);
+    const int y = pix / W, x = pix - y * W;
+    const float* low = low_all + (size_t)frame * low_frame_stride + low_layer_off;
+    int sy0 = yofs[y], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= lh ? lh - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= lh ? lh - 1 : sy1);
+    const int sx0 = xofs[x];
+    const float* S0 = low + (size_t)sy0 * lw * C;
+    const float* S1 = low + (size_t)sy1 * lw * C;
+    float h0, h1;
+    if (sx0 + 1 >= lw) {  // dx >= xmax: D = S[sx]*ONE
+        h0 = S0[(size_t)sx0 * C + c] * 1.f;
+        h1 = S1[(size_t)sx0 * C + c] * 1.f;
+    } else {
+        const float a0 = ax0[x], a1 = ax1[x];
+        h0 = S0[(size_t)sx0 * C + c] * a0 + S0[(size_t)(sx0 + 1) * C + c] * a1;
+        h1 = S1[(size_t)sx0 * C + c] * a0 + S1[(size_t)(sx0 + 1) * C + c] * a1;
+    }
+    post_all[(size_t)frame * post_frame_stride + post_layer_off + e] = h0 * ay0[y] + h1 * ay1[y];
+}
+
+void launch_upsample_pack(const FrameGeom& g, const DeviceForest& f, const UpsampleTables& t,
+                          const float* d_low, float* d_post, int n, hipStream_t s) {
+    const size_t low_frame = (size_t)g.lw * g.lh * f.sum_classes;
+    const size_t post_frame = (size_t)g.W * g.H * f.sum_classes;
+    int prefix = 0;
+    for (int l = 0; l < f.n_layers; l++) {
+        const int C = f.class_counts[l];
+        const size_t total = (size_t)g.W * g.H * C * n;
+        upsample_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            g.W, g.H, g.lw, g.lh, C, low_frame, (size_t)g.lw * g.lh * prefix, post_frame, (size_t)g.W * g.H * prefix,
+            t.xofs.as<int>(), t.ax0.as<float>(), t.ax1.as<float>(), t.yofs.as<int>(), t.ay0.as<float>(), t.ay1.as<float>(),
+            d_low, d_post, total);
+        prefix += C;
+    }
+}
+
+// =============================================================================================
+// label rules, one thread per point
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+labels_kernel(const float* __restrict__ values, size_t n_points, int C, int mode, int unknown, int8_t* __restrict__ labels) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_points) return;
+    const float* v = values + i * C;
+    int best;
+    float mx;
+    if (mode == RVSEG_LABEL_EVAL) {           // test.cpp:160-175
+        best = -1; mx = -1000.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == RVSEG_LABEL_CRF) {     // segmenter.cpp:646-657
+        best = unknown; mx = (float)(2.0 / (double)C);
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == RVSEG_LABEL_NOCRF) {   // segmenter.cpp:664-679
+        best = unknown; mx = -1000.f;
+        float sum = 0.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; sum += x; if (x > mx) { mx = x; best = c; } }
+        if (!(sum != 0.0f)) best = unknown;
+    } else {                                   // densecrf.cpp:202-211
+        best = 0; mx = v[0];
+        for (int c = 1; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    }
+    labels[i] = (int8_t)best;
+}
+
+void launch_labels(const float* d_values, size_t n_points, int C, int mode, int unknown, int8_t* d_labels, hipStream_t s) {
+    if (n_points == 0) return;
+    labels_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(d_values, n_points, C, mode, unknown, d_labels);
 }
 
 }  // namespace rvseg

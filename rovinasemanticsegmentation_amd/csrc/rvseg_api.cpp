@@ -300,13 +300,26 @@ rvseg_status rvseg_forest_eval(rvseg_ctx* ctx, const float* X, int32_t P, int32_
 int32_t rvseg_last_timing(const rvseg_ctx* ctx, char* names_out, size_t names_cap, float* ms_out, int32_t max_stages) {
     if (!ctx) return 0;
     const auto& t = ctx->timer;
-    std::string joined;
-    for (size_t i = 0; i < t.names.size(); i++) { if (i) joined += ';'; joined += t.names[i]; }
-    if (names_out && names_cap) {
-        std::snprintf(names_out, names_cap, "%s", joined.c_str());
+    // events[i] starts stage names[i]; the next event ends it.  Same-named stages accumulate.
+    std::vector<std::string> names;
+    std::vector<float> ms;
+    if (t.used >= 2) {
+        (void)hipEventSynchronize(t.events[t.used - 1]);
+        for (size_t i = 0; i + 1 < t.used; i++) {
+            if (t.names[i] == "end") continue;
+            float v = 0.f;
+            if (hipEventElapsedTime(&v, t.events[i], t.events[i + 1]) != hipSuccess) v = 0.f;
+            size_t k = 0;
+            for (; k < names.size(); k++) if (names[k] == t.names[i]) break;
+            if (k == names.size()) { names.push_back(t.names[i]); ms.push_back(0.f); }
+            ms[k] += v;
+        }
     }
-    int n = (int)t.ms.size();
-    for (int i = 0; i < n && i < max_stages; i++) if (ms_out) ms_out[i] = t.ms[i];
+    std::string joined;
+    for (size_t i = 0; i < names.size(); i++) { if (i) joined += ';'; joined += names[i]; }
+    if (names_out && names_cap) std::snprintf(names_out, names_cap, "%s", joined.c_str());
+    const int n = (int)ms.size();
+    for (int i = 0; i < n && i < max_stages; i++) if (ms_out) ms_out[i] = ms[i];
     return n;
 }
 

@@ -44,8 +44,9 @@ struct LabTables {
 };
 
 struct StageTimer {
-    std::vector<std::string> names;
-    std::vector<hipEvent_t> events;  // events[i] .. events[i+1] bracket stage i
+    std::vector<std::string> names;  // names[i] = stage that starts at events[i]
+    std::vector<hipEvent_t> events;  // pool; events[i] .. events[i+1] bracket stage i
+    size_t used = 0;
     std::vector<float> ms;
 };
 

@@ -1,13 +1,350 @@
-// placeholder: frame / CRF pipelines (filled in next)
+// Frame pipeline: host orchestration of the per-frame hot path over batches of key frames
+// (replaces the body of Segmenter::processFramesFromQueueInternalRF, src/segmenter.cpp:351-431,
+// and -- with use_dense_crf -- the DenseCRF call shape of src/segmenter.cpp:639-657 per frame).
+#include <cmath>
+#include <cstring>
+
 #include "rvseg_internal.h"
-extern "C" {
-void rvseg_pipeline_destroy(rvseg_ctx*) {}
-#define NOT_YET(ctx) do { if (ctx) (ctx)->err = "not implemented yet"; return RVSEG_ERR_INVALID_ARG; } while (0)
-rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t*, const uint16_t*, const float*, float*, int32_t*, int32_t*, int32_t*) { NOT_YET(ctx); }
-rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t, const uint8_t*, const uint16_t*, const float*, float*, float*, int8_t*) { NOT_YET(ctx); }
-rvseg_status rvseg_segment_frames_device(rvseg_ctx* ctx, int32_t, const uint8_t*, const uint16_t*, const float*, float*, float*, int8_t*, void*) { NOT_YET(ctx); }
-rvseg_status rvseg_crf_infer(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const float*, const float*, float, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
-rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const int32_t*, const float* const*, const float*, const float*, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
-rvseg_status rvseg_lattice_build(rvseg_ctx* ctx, const float*, int32_t, int32_t, int32_t*, float*, int16_t*, int32_t, int32_t*) { NOT_YET(ctx); }
-rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float*, int32_t, float*) { NOT_YET(ctx); }
+#include "rvseg_kernels.h"
+#include "rvseg_pipeline.h"
+
+namespace rvseg {
+
+// ---- cv::resize coefficient rule (OpenCV 2.4 imgwarp.cpp), identical to the oracle's statement
+static void resize_coeffs(int ssize, int dsize, bool clamp_weights, std::vector<int>& ofs,
+                          std::vector<float>& w0, std::vector<float>& w1) {
+    ofs.resize(dsize); w0.resize(dsize); w1.resize(dsize);
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (clamp_weights) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s; w0[d] = 1.f - f; w1[d] = f;
+    }
 }
+
+static rvseg_status upload(rvseg_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+    rvseg_status st = dev_alloc(ctx, b, bytes);
+    if (st != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RVSEG_OK;
+}
+
+rvseg_status pipeline_init(rvseg_ctx* ctx) {
+    if (ctx->impl) return RVSEG_OK;
+    const rvseg_params& p = ctx->params;
+    if (p.width % p.stride != 0 || p.height % p.stride != 0) {
+        // the reference would scatter outside its low-res image (segmenter.cpp:357,370)
+        ctx->err = "width and height must be multiples of rf_prediction_stride";
+        return RVSEG_ERR_INVALID_ARG;
+    }
+    if (p.patch_size_reduce > 16) { ctx->err = "patch_size_reduce > 16 is not supported"; return RVSEG_ERR_INVALID_ARG; }
+    Pipeline* im = new Pipeline();
+    ctx->impl = reinterpret_cast<rvseg_ctx::Impl*>(im);
+    FrameGeom& g = im->geom;
+    g.W = p.width; g.H = p.height; g.stride = p.stride;
+    g.lw = p.width / p.stride; g.lh = p.height / p.stride;
+    g.depth_min = p.depth_min; g.depth_max = p.depth_max;
+    g.dmin_mm = (float)(p.depth_min * 1000.0); g.dmax_mm = (float)(p.depth_max * 1000.0);  // feature_extractor.h:43-44
+    g.patch_size = p.patch_size; g.r = p.patch_size_reduce;
+    g.n_patch = p.feature_color_patch ? g.r * g.r * 3 : 0;
+    int pos = g.n_patch;
+    g.pos_depth = p.feature_depth ? pos++ : -1;
+    g.pos_height = p.feature_height ? pos++ : -1;
+    g.pos_normal = p.feature_normal ? pos++ : -1;
+    g.D = pos;
+    g.fill = p.fill_value;
+
+    rvseg_status st;
+    // 8-bit patch resize tables, one row per ROI half size
+    if (p.feature_color_patch) {
+        const int max_half = (int)(p.patch_size / (2.0 * p.depth_min));
+        std::vector<ResizeRow> rows((size_t)max_half + 1);
+        std::vector<int> ofs; std::vector<float> w0, w1;
+        for (int half = 0; half <= max_half; half++) {
+            const int size = 2 * half + 1;
+            ResizeRow& rr = rows[half];
+            std::memset(&rr, 0, sizeof(rr));
+            resize_coeffs(size, g.r, true, ofs, w0, w1);
+            for (int d = 0; d < g.r; d++) {
+                rr.xofs[d] = (int16_t)ofs[d];
+                rr.ia0[d] = (int16_t)std::lrintf(w0[d] * 2048.f);  // saturate_cast<short>: round half to even
+                rr.ia1[d] = (int16_t)std::lrintf(w1[d] * 2048.f);
+            }
+            resize_coeffs(size, g.r, false, ofs, w0, w1);
+            for (int d = 0; d < g.r; d++) {
+                rr.yofs[d] = (int16_t)ofs[d];
+                rr.ib0[d] = (int16_t)std::lrintf(w0[d] * 2048.f);
+                rr.ib1[d] = (int16_t)std::lrintf(w1[d] * 2048.f);
+            }
+        }
+        if ((st = upload(ctx, im->resize_rows, rows.data(), rows.size() * sizeof(ResizeRow))) != RVSEG_OK) return st;
+    }
+    // float up-sampling tables
+    {
+        std::vector<int> ofs; std::vector<float> w0, w1;
+        resize_coeffs(g.lw, g.W, true, ofs, w0, w1);
+        if ((st = upload(ctx, im->up.xofs, ofs.data(), ofs.size() * 4)) != RVSEG_OK) return st;
+        if ((st = upload(ctx, im->up.ax0, w0.data(), w0.size() * 4)) != RVSEG_OK) return st;
+        if ((st = upload(ctx, im->up.ax1, w1.data(), w1.size() * 4)) != RVSEG_OK) return st;
+        resize_coeffs(g.lh, g.H, false, ofs, w0, w1);
+        if ((st = upload(ctx, im->up.yofs, ofs.data(), ofs.size() * 4)) != RVSEG_OK) return st;
+        if ((st = upload(ctx, im->up.ay0, w0.data(), w0.size() * 4)) != RVSEG_OK) return st;
+        if ((st = upload(ctx, im->up.ay1, w1.data(), w1.size() * 4)) != RVSEG_OK) return st;
+    }
+    return RVSEG_OK;
+}
+
+static void pipeline_free(Pipeline* im) {
+    DevBuf* all[] = {&im->resize_rows, &im->up.xofs, &im->up.ax0, &im->up.ax1, &im->up.yofs, &im->up.ay0, &im->up.ay1,
+                     &im->calibA, &im->lab, &im->cloud, &im->rect, &im->nfeat, &im->low, &im->post, &im->marg,
+                     &im->labels, &im->in_rgb, &im->in_depth, &im->dump, &im->valid};
+    for (DevBuf* b : all) dev_free(*b);
+    if (im->h_calibA) (void)hipHostFree(im->h_calibA);
+    crf_state_free(im);
+}
+
+// A = R*Kinv, Eigen fixed 3x3 product accumulated left to right (feature_extractor.h:223)
+static void calib_to_A(const float* calib, float* out12) {
+    const float *Kinv = calib, *R = calib + 9, *t = calib + 18;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            out12[i * 3 + j] = (R[i * 3 + 0] * Kinv[0 * 3 + j] + R[i * 3 + 1] * Kinv[1 * 3 + j]) + R[i * 3 + 2] * Kinv[2 * 3 + j];
+    out12[9] = t[0]; out12[10] = t[1]; out12[11] = t[2];
+}
+
+static rvseg_status upload_calib(rvseg_ctx* ctx, Pipeline* im, const float* calib, int n, hipStream_t s) {
+    if ((size_t)n * 12 * sizeof(float) > im->h_calibA_bytes) {
+        if (im->h_calibA) (void)hipHostFree(im->h_calibA);
+        im->h_calibA = nullptr;
+        im->h_calibA_bytes = (size_t)n * 12 * sizeof(float);
+        RV_HIP(ctx, hipHostMalloc((void**)&im->h_calibA, im->h_calibA_bytes, hipHostMallocDefault));
+    }
+    for (int i = 0; i < n; i++) calib_to_A(calib + (size_t)i * 21, im->h_calibA + (size_t)i * 12);
+    rvseg_status st = dev_reserve(ctx, im->calibA, (size_t)n * 12 * sizeof(float));
+    if (st != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpyAsync(im->calibA.p, im->h_calibA, (size_t)n * 12 * sizeof(float), hipMemcpyHostToDevice, s));
+    return RVSEG_OK;
+}
+
+// ---- stage timing ----------------------------------------------------------------------------
+void timer_reset(rvseg_ctx* ctx) {
+    ctx->timer.names.clear();
+    ctx->timer.ms.clear();
+    ctx->timer.used = 0;
+}
+
+void timer_mark(rvseg_ctx* ctx, const char* name, hipStream_t s) {
+    StageTimer& t = ctx->timer;
+    if (t.used >= t.events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        t.events.push_back(e);
+    }
+    (void)hipEventRecord(t.events[t.used++], s);
+    t.names.push_back(name);
+}
+
+// ---- the frame path for one chunk of at most max_batch frames ----------------------------------
+static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, const uint16_t* d_depth,
+                              const float* d_calibA, float* d_post, float* d_marg, int8_t* d_labels, hipStream_t s) {
+    const FrameGeom& g = im->geom;
+    const rvseg_params& p = ctx->params;
+    const DeviceForest& f = ctx->forest;
+    const size_t npix = (size_t)g.W * g.H;
+    rvseg_status st;
+    const bool need_cloud = p.feature_height || p.feature_normal || p.use_dense_crf;
+    if (p.feature_color_patch && (st = dev_reserve(ctx, im->lab, npix * 4 * n)) != RVSEG_OK) return st;
+    if (need_cloud && (st = dev_reserve(ctx, im->cloud, npix * 16 * n)) != RVSEG_OK) return st;
+    if (p.feature_normal) {
+        if ((st = dev_reserve(ctx, im->rect, npix * n)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, im->nfeat, (size_t)g.lw * g.lh * 4 * n)) != RVSEG_OK) return st;
+    }
+    if ((st = dev_reserve(ctx, im->low, (size_t)g.lw * g.lh * f.sum_classes * 4 * n)) != RVSEG_OK) return st;
+    float* post = d_post;
+    if (!post) {
+        if ((st = dev_reserve(ctx, im->post, npix * f.sum_classes * 4 * n)) != RVSEG_OK) return st;
+        post = im->post.as<float>();
+    }
+    timer_mark(ctx, "prep", s);
+    launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
+                need_cloud ? im->cloud.as<float4>() : nullptr, n, s);
+    if (p.feature_normal) {
+        timer_mark(ctx, "window_map", s);
+        launch_window_map(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), n, s);
+        timer_mark(ctx, "normal_feature", s);
+        launch_normal_feature(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), im->nfeat.as<float>(), n, s);
+    }
+    timer_mark(ctx, "rf_frames", s);
+    launch_rf_frames(g, f, im->resize_rows.as<ResizeRow>(), im->lab.as<uint32_t>(), d_depth, im->cloud.as<float4>(),
+                     im->nfeat.as<float>(), im->low.as<float>(), nullptr, nullptr, n, s);
+    timer_mark(ctx, "upsample_pack", s);
+    launch_upsample_pack(g, f, im->up, im->low.as<float>(), post, n, s);
+    if (p.use_dense_crf) {
+        st = crf_frames(ctx, im, n, d_rgb, post, d_marg, d_labels, s);
+        if (st != RVSEG_OK) return st;
+    } else if (d_labels) {
+        timer_mark(ctx, "labels", s);
+        size_t loff = 0;
+        int prefix = 0;
+        for (int i = 0; i < n; i++) {
+            prefix = 0;
+            for (int l = 0; l < f.n_layers; l++) {
+                launch_labels(post + (size_t)i * npix * f.sum_classes + npix * prefix, npix, f.class_counts[l], p.label_mode,
+                              p.unknown_label[l], d_labels + loff, s);
+                loff += npix;
+                prefix += f.class_counts[l];
+            }
+        }
+    }
+    timer_mark(ctx, "end", s);
+    RV_HIP(ctx, hipGetLastError());
+    return RVSEG_OK;
+}
+
+}  // namespace rvseg
+
+using namespace rvseg;
+
+extern "C" {
+
+void rvseg_pipeline_destroy(rvseg_ctx* ctx) {
+    if (!ctx || !ctx->impl) return;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    pipeline_free(im);
+    delete im;
+    ctx->impl = nullptr;
+}
+
+rvseg_status rvseg_segment_frames_device(rvseg_ctx* ctx, int32_t n_frames, const uint8_t* d_rgb,
+                                         const uint16_t* d_depth_mm, const float* calib, float* d_posteriors_out,
+                                         float* d_marginals_out, int8_t* d_labels_out, void* hip_stream) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) { ctx->err = "no forest loaded"; return RVSEG_ERR_NO_FOREST; }
+    if (n_frames < 0 || (n_frames > 0 && (!d_rgb || !d_depth_mm || !calib))) { ctx->err = "bad arguments"; return RVSEG_ERR_INVALID_ARG; }
+    if (n_frames == 0) return RVSEG_OK;
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    rvseg_status st = pipeline_init(ctx);
+    if (st != RVSEG_OK) return st;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    timer_reset(ctx);
+    if ((st = upload_calib(ctx, im, calib, n_frames, s)) != RVSEG_OK) return st;
+    const FrameGeom& g = im->geom;
+    const size_t npix = (size_t)g.W * g.H;
+    const size_t S = (size_t)ctx->forest.sum_classes, L = (size_t)ctx->forest.n_layers;
+    for (int start = 0; start < n_frames; start += ctx->params.max_batch) {
+        const int n = std::min(ctx->params.max_batch, n_frames - start);
+        st = run_chunk(ctx, im, n, d_rgb + (size_t)start * npix * 3, d_depth_mm + (size_t)start * npix,
+                       im->calibA.as<float>() + (size_t)start * 12,
+                       d_posteriors_out ? d_posteriors_out + (size_t)start * npix * S : nullptr,
+                       d_marginals_out ? d_marginals_out + (size_t)start * npix * S : nullptr,
+                       d_labels_out ? d_labels_out + (size_t)start * npix * L : nullptr, s);
+        if (st != RVSEG_OK) return st;
+    }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_t* rgb, const uint16_t* depth_mm,
+                                  const float* calib, float* posteriors_out, float* marginals_out, int8_t* labels_out) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) { ctx->err = "no forest loaded"; return RVSEG_ERR_NO_FOREST; }
+    if (n_frames < 0 || (n_frames > 0 && (!rgb || !depth_mm || !calib))) { ctx->err = "bad arguments"; return RVSEG_ERR_INVALID_ARG; }
+    if (n_frames == 0) return RVSEG_OK;
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    rvseg_status st = pipeline_init(ctx);
+    if (st != RVSEG_OK) return st;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    const FrameGeom& g = im->geom;
+    const size_t npix = (size_t)g.W * g.H;
+    const size_t S = (size_t)ctx->forest.sum_classes, L = (size_t)ctx->forest.n_layers;
+    const bool want_marg = marginals_out && ctx->params.use_dense_crf;
+    hipStream_t s = ctx->stream;
+    // stage through HBM in chunks of max_batch frames
+    for (int start = 0; start < n_frames; start += ctx->params.max_batch) {
+        const int n = std::min(ctx->params.max_batch, n_frames - start);
+        if ((st = dev_reserve(ctx, im->in_rgb, npix * 3 * n)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, im->in_depth, npix * 2 * n)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, im->post, npix * S * 4 * n)) != RVSEG_OK) return st;
+        if (want_marg && (st = dev_reserve(ctx, im->marg, npix * S * 4 * n)) != RVSEG_OK) return st;
+        if (labels_out && (st = dev_reserve(ctx, im->labels, npix * L * n)) != RVSEG_OK) return st;
+        RV_HIP(ctx, hipMemcpyAsync(im->in_rgb.p, rgb + (size_t)start * npix * 3, npix * 3 * n, hipMemcpyHostToDevice, s));
+        RV_HIP(ctx, hipMemcpyAsync(im->in_depth.p, depth_mm + (size_t)start * npix, npix * 2 * n, hipMemcpyHostToDevice, s));
+        timer_reset(ctx);
+        if ((st = upload_calib(ctx, im, calib + (size_t)start * 21, n, s)) != RVSEG_OK) return st;
+        st = run_chunk(ctx, im, n, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
+                       im->post.as<float>(), want_marg ? im->marg.as<float>() : nullptr,
+                       labels_out ? im->labels.as<int8_t>() : nullptr, s);
+        if (st != RVSEG_OK) return st;
+        if (posteriors_out)
+            RV_HIP(ctx, hipMemcpyAsync(posteriors_out + (size_t)start * npix * S, im->post.p, npix * S * 4 * n, hipMemcpyDeviceToHost, s));
+        if (want_marg)
+            RV_HIP(ctx, hipMemcpyAsync(marginals_out + (size_t)start * npix * S, im->marg.p, npix * S * 4 * n, hipMemcpyDeviceToHost, s));
+        if (labels_out)
+            RV_HIP(ctx, hipMemcpyAsync(labels_out + (size_t)start * npix * L, im->labels.p, npix * L * n, hipMemcpyDeviceToHost, s));
+        RV_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const uint16_t* depth_mm, const float* calib,
+                                    float* feat_out, int32_t* x_v, int32_t* y_v, int32_t* n_points) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!rgb || !depth_mm || !calib || !feat_out || !x_v || !y_v || !n_points) { ctx->err = "null argument"; return RVSEG_ERR_INVALID_ARG; }
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    rvseg_status st = pipeline_init(ctx);
+    if (st != RVSEG_OK) return st;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    const FrameGeom& g = im->geom;
+    const rvseg_params& p = ctx->params;
+    const size_t npix = (size_t)g.W * g.H;
+    const int P = g.lw * g.lh;
+    hipStream_t s = ctx->stream;
+    if ((st = dev_reserve(ctx, im->in_rgb, npix * 3)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->in_depth, npix * 2)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->lab, npix * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->cloud, npix * 16)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->rect, npix)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->nfeat, (size_t)P * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->dump, (size_t)P * g.D * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->valid, (size_t)P)) != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpyAsync(im->in_rgb.p, rgb, npix * 3, hipMemcpyHostToDevice, s));
+    RV_HIP(ctx, hipMemcpyAsync(im->in_depth.p, depth_mm, npix * 2, hipMemcpyHostToDevice, s));
+    if ((st = upload_calib(ctx, im, calib, 1, s)) != RVSEG_OK) return st;
+    launch_prep(g, ctx->lab, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
+                im->lab.as<uint32_t>(), im->cloud.as<float4>(), 1, s);
+    if (p.feature_normal) {
+        launch_window_map(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), 1, s);
+        launch_normal_feature(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), im->nfeat.as<float>(), 1, s);
+    }
+    // the dump variant never touches the forest; a context without a model can still extract
+    DeviceForest none = ctx->forest;
+    launch_rf_frames(g, none, im->resize_rows.as<ResizeRow>(), im->lab.as<uint32_t>(), im->in_depth.as<uint16_t>(),
+                     im->cloud.as<float4>(), im->nfeat.as<float>(), nullptr, im->dump.as<float>(), im->valid.as<uint8_t>(), 1, s);
+    RV_HIP(ctx, hipGetLastError());
+    std::vector<float> dump((size_t)P * g.D);
+    std::vector<uint8_t> valid((size_t)P);
+    RV_HIP(ctx, hipMemcpyAsync(dump.data(), im->dump.p, dump.size() * 4, hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipMemcpyAsync(valid.data(), im->valid.p, valid.size(), hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipStreamSynchronize(s));
+    // compact in the order of the reference's stride-grid scan (feature_extractor.h:56-71)
+    int n = 0;
+    for (int ly = 0; ly < g.lh; ly++)
+        for (int lx = 0; lx < g.lw; lx++) {
+            const size_t pi = (size_t)ly * g.lw + lx;
+            if (!valid[pi]) continue;
+            std::memcpy(feat_out + (size_t)n * g.D, dump.data() + pi * g.D, (size_t)g.D * 4);
+            x_v[n] = lx * g.stride;
+            y_v[n] = ly * g.stride;
+            n++;
+        }
+    *n_points = n;
+    return RVSEG_OK;
+}
+
+}  // extern "C"

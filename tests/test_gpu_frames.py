@@ -1,0 +1,117 @@
+"""GPU parity of the frame path (features -> forest -> up-sample -> pack -> labels) through the
+C ABI against the CPU oracle: bit-exact features, log-posteriors and labels."""
+import numpy as np
+import pytest
+
+from rovinasemanticsegmentation_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_case(seed, W=96, H=64, lo=500, hi=15000):
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ys, xs = np.mgrid[0:H, 0:W]
+    depth = (lo + (hi - lo) * ((xs + 2 * ys) % 97) / 96.0).astype(np.uint16)
+    depth[rng.random((H, W)) < 0.08] = 0
+    depth[5:9, 5:40] = 400          # below depth_min
+    depth[20:24, 50:60] = 15001     # above depth_max
+    return rgb, depth
+
+
+def test_extract_features_full_frame_with_holes(gpu_ctx_factory, oracle):
+    rgb, depth = synthetic.make_frame(3, holes=True)
+    calib = synthetic.make_calib()
+    want, wx, wy = oracle.extract(oracle.default_params(), rgb, depth, calib)
+    ctx = gpu_ctx_factory()
+    got, gx, gy = ctx.extract_features(rgb, depth, calib)
+    assert np.array_equal(gx, wx) and np.array_equal(gy, wy)
+    assert got.shape == want.shape
+    for name, sl in (("patch", slice(0, 363)), ("depth", slice(363, 364)), ("height", slice(364, 365)), ("normal", slice(365, 366))):
+        assert np.array_equal(got[:, sl], want[:, sl]), name
+    assert (want[:, 365] == -2).any() and (want[:, 365] > 0).any()
+
+
+@pytest.mark.parametrize("stride,patch,r", [(1, 7, 3), (2, 9, 4), (4, 5, 2)])
+def test_extract_features_small_configs(gpu_ctx_factory, oracle, stride, patch, r):
+    W, H = 96, 64
+    rgb, depth = _small_case(stride)
+    kw = dict(width=W, height=H, stride=stride, patch_size=patch, patch_size_reduce=r)
+    calib = synthetic.make_calib(W, H)
+    want, wx, wy = oracle.extract(oracle.default_params(**kw), rgb, depth, calib)
+    ctx = gpu_ctx_factory(**kw)
+    got, gx, gy = ctx.extract_features(rgb, depth, calib)
+    assert np.array_equal(gx, wx) and np.array_equal(gy, wy)
+    assert np.array_equal(got, want)
+
+
+def test_extract_feature_toggles(gpu_ctx_factory, oracle):
+    W, H = 96, 64
+    rgb, depth = _small_case(9)
+    calib = synthetic.make_calib(W, H)
+    for kw in (dict(feature_normal=0), dict(feature_color_patch=0), dict(feature_depth=0, feature_height=0)):
+        kw = dict(width=W, height=H, patch_size=9, patch_size_reduce=3, **kw)
+        want, wx, wy = oracle.extract(oracle.default_params(**kw), rgb, depth, calib)
+        ctx = gpu_ctx_factory(**kw)
+        got, gx, gy = ctx.extract_features(rgb, depth, calib)
+        assert got.shape == want.shape and np.array_equal(got, want), kw
+
+
+def test_near_plane_uses_full_reflected_border(gpu_ctx_factory, oracle):
+    # depth 0.5 m -> half = 77 = the whole reflected border (feature_extractor.h:37,140)
+    rgb, _ = synthetic.make_frame(0)
+    depth = np.full((480, 640), 500, np.uint16)
+    depth[:, 320:] = 15000       # half = 2 -> 5x5 ROI (up-sampling branch of the resize)
+    calib = synthetic.make_calib()
+    p = oracle.default_params(feature_normal=0)
+    want, wx, wy = oracle.extract(p, rgb, depth, calib)
+    ctx = gpu_ctx_factory(feature_normal=0)
+    got, gx, gy = ctx.extract_features(rgb, depth, calib)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("multi,fill", [(1, 0.0), (0, -1000.0)])
+def test_rf_frames_bit_exact(gpu_ctx_factory, oracle, multi, fill):
+    blob = synthetic.make_forest_bytes(seed=11, n_trees=4, leaves_per_tree=2048, max_depth=24)
+    rgb, depth = synthetic.make_batch(3, holes=True)
+    calib = synthetic.make_calib()
+    forest = oracle.Forest(blob)
+    ctx = gpu_ctx_factory(multi_layer=multi, fill_value=fill, max_batch=2, label_mode=0 if multi == 0 else 2)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    p = oracle.default_params(fill_value=fill)
+    cc = forest.classes(multi)
+    N = 640 * 480
+    for i in range(3):
+        want, P = oracle.rf_frame(p, forest, multi, rgb[i], depth[i], calib)
+        assert 0 < P < 76800
+        assert np.array_equal(out["posteriors"][i], want), i
+        off = 0
+        for l, C in enumerate(cc):
+            wl = oracle.labels(want[off:off + N * C], C, 0 if multi == 0 else 2, unknown=[7, 8][l])
+            assert np.array_equal(out["labels"][i, l].ravel(), wl)
+            off += N * C
+    # the eval-tool rule yields -1 only where nothing beats -1000
+    if multi == 0:
+        assert out["labels"].min() >= -1
+
+
+def test_rf_frames_small_odd_sizes(gpu_ctx_factory, oracle):
+    W, H = 100, 52   # not multiples of the distance-map tile; stride 2
+    rgb, depth = _small_case(21, W, H)
+    kw = dict(width=W, height=H, patch_size=9, patch_size_reduce=3)
+    blob = synthetic.make_forest_bytes(seed=4, n_trees=3, leaves_per_tree=128, max_depth=10, D=30)
+    forest = oracle.Forest(blob)
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb[None], depth[None], calib)
+    want, _ = oracle.rf_frame(oracle.default_params(**kw), forest, 1, rgb, depth, calib)
+    assert np.array_equal(out["posteriors"][0], want)
+
+
+def test_stride_must_divide_image(gpu_ctx_factory):
+    import rovinasemanticsegmentation_amd as rv
+    ctx = gpu_ctx_factory(width=101, height=52, patch_size=9, patch_size_reduce=3, feature_color_patch=0)
+    with pytest.raises(rv.capi.RvsegError):
+        ctx.extract_features(np.zeros((52, 101, 3), np.uint8), np.zeros((52, 101), np.uint16), synthetic.make_calib(101, 52))
