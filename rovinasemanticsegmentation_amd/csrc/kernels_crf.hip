@@ -1,0 +1,503 @@
+// Permutohedral lattice + DenseCRF mean-field kernels for gfx950.
+//
+// Reference semantics (third-party/densecrf/src):
+//   Permutohedral::init  SSE branch   permutohedral.cpp:140-321   (elevate, round-half-even,
+//                                     rank, barycentric, d+1 vertex keys per point, blur neighbours)
+//   sseCompute / seqCompute           permutohedral.cpp:476-589   (splat, blur over d+1 axes, slice)
+//   DenseKernel::initLattice/filter   pairwise.cpp:40-80          (symmetric normalisation)
+//   PottsCompatibility::apply         labelcompatibility.cpp:46-48
+//   expAndNormalize, inference        densecrf.cpp:98-131
+//
+// MI355X design notes
+//   * One open-addressing hash table in HBM holds the lattice vertices of ALL frames of a chunk
+//     (the frame index is an extra key coordinate), so every later kernel is a flat launch over
+//     global vertex / point indices with no per-frame loop.
+//   * Vertex numbering is whatever the atomics produce; no result depends on it.
+//   * The reference splats sequentially over points, so a vertex's fp32 sum is ordered by point
+//     index.  To stay bit-exact the splat is a GATHER: entries are stably sorted by vertex and each
+//     (vertex, class) chain adds its contributions in ascending point order.  No float atomics.
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_math.h"
+#include "rvseg_crf.h"
+
+namespace rvseg {
+
+// ---------------------------------------------------------------------------------------------
+// hash table
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_EMPTY = -1, ST_LOCKED = -2, ST_FILLED = 0;
+
+struct Key8 { short k[8]; };  // d coordinates, then the frame index at k[7]; unused = 0
+
+__device__ __forceinline__ unsigned hash_key(const Key8& key) {
+    const unsigned* w = reinterpret_cast<const unsigned*>(key.k);
+    unsigned h = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h ^= w[i];
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 15;
+    }
+    return h;
+}
+
+__device__ __forceinline__ bool key_equal_at(const unsigned long long* tkeys, unsigned slot, const Key8& key) {
+    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+    // agent-scope loads: another CU may have written the key after this CU cached the line
+    const unsigned long long a = __hip_atomic_load(tkeys + 2 * (size_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(tkeys + 2 * (size_t)slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return a == mine[0] && b == mine[1];
+}
+
+// find-or-create; returns the slot.  On overflow sets counters[1] and returns 0.
+__device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* tkeys, unsigned mask, int* counters,
+                                                const Key8& key) {
+    unsigned h = hash_key(key) & mask;
+    for (unsigned probes = 0; probes <= mask; ) {
+        int st = __hip_atomic_load(state + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_EMPTY) {
+            int expected = ST_EMPTY;
+            if (__hip_atomic_compare_exchange_strong(state + h, &expected, ST_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+                __hip_atomic_store(tkeys + 2 * (size_t)h, mine[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(tkeys + 2 * (size_t)h + 1, mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(state + h, ST_FILLED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                const int filled = atomicAdd(counters + 2, 1) + 1;
+                if ((unsigned)filled > (mask >> 1) + 1) counters[1] = 1;  // load factor above 1/2
+                return h;
+            }
+            continue;  // lost the race: look at the same slot again
+        }
+        if (st == ST_LOCKED) continue;  // the owner publishes within its own loop iteration
+        if (key_equal_at(tkeys, h, key)) return h;
+        h = (h + 1) & mask;
+        probes++;
+    }
+    counters[1] = 1;
+    return 0;
+}
+
+// read-only lookup (table complete, written by earlier kernels)
+__device__ __forceinline__ int hash_lookup(const int* state, const unsigned long long* tkeys, unsigned mask, const Key8& key) {
+    unsigned h = hash_key(key) & mask;
+    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+    for (unsigned probes = 0; probes <= mask; probes++) {
+        if (state[h] == ST_EMPTY) return -1;
+        if (tkeys[2 * (size_t)h] == mine[0] && tkeys[2 * (size_t)h + 1] == mine[1]) return (int)h;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Permutohedral::init per point (SSE branch semantics, fp32, no contraction)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256)
+lattice_points_kernel(LatticeDev L, FeatureSource fs) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_frame = L.Npad;
+    if (gid >= per_frame * L.n_frames) return;
+    const int frame = (int)(gid / per_frame);
+    const int i = (int)(gid - (long long)frame * per_frame);
+    const bool real = i < L.N;
+    const long long gp = (long long)frame * L.N + i;  // global point index (valid when real)
+
+    float f[D];
+    if (!real) {
+#pragma unroll
+        for (int k = 0; k < D; k++) f[k] = 0.0f;  // padded lanes carry zero features (permutohedral.cpp:196)
+    } else if (fs.mode == 0) {
+#pragma unroll
+        for (int k = 0; k < D; k++) f[k] = fs.feat[gp * D + k];
+    } else {
+        // frame mode (D == 6): segmenter.cpp:629-637 on the frame's own points
+        const float4 c = fs.cloud[gp];
+        float x = c.x, y = c.y, z = c.z;
+        if (!(finite_f(x) && finite_f(y) && finite_f(z))) x = y = z = 0.0f;
+        const uint8_t* px = fs.rgb + gp * 3;
+        const float v[6] = {x * fs.xyz_kernel, y * fs.xyz_kernel, z * fs.xyz_kernel,
+                            ((float)px[0] / 255.0f) * fs.rgb_kernel, ((float)px[1] / 255.0f) * fs.rgb_kernel,
+                            ((float)px[2] / 255.0f) * fs.rgb_kernel};
+#pragma unroll
+        for (int k = 0; k < D; k++) f[k] = v[k < 6 ? k : 0];
+    }
+
+    const float invdplus1 = 1.0f / (D + 1), dplus1 = (float)(D + 1);
+    float el[D + 1], rem0[D + 1], rank[D + 1];
+    // elevate (permutohedral.cpp:201-207)
+    float sm = 0.0f;
+#pragma unroll
+    for (int j = D; j > 0; j--) {
+        const float cf = f[j - 1] * L.scale[j - 1];
+        el[j] = sm - (float)j * cf;
+        sm += cf;
+    }
+    el[0] = sm;
+    // closest 0-coloured simplex (:210-220), cvtps_epi32 = round half to even
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= D; k++) {
+        float v = invdplus1 * el[k];
+        v = rintf(v);
+        rem0[k] = v * dplus1;
+        sum += v;
+    }
+    // rank (:223-233)
+#pragma unroll
+    for (int k = 0; k <= D; k++) rank[k] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+        const float di = el[a] - rem0[a];
+#pragma unroll
+        for (int b = a + 1; b <= D; b++) {
+            const float dj = el[b] - rem0[b];
+            const float c = di < dj ? 1.0f : 0.0f;
+            rank[a] += c;
+            rank[b] += 1.0f - c;
+        }
+    }
+    // back onto the plane (:236-242)
+#pragma unroll
+    for (int k = 0; k <= D; k++) {
+        rank[k] += sum;
+        const float add = rank[k] < 0.0f ? dplus1 : 0.0f;
+        const float sub = rank[k] >= dplus1 ? dplus1 : 0.0f;
+        rank[k] += add - sub;
+        rem0[k] += add - sub;
+    }
+    // barycentric (:245-263); the scatter index D - rank is data dependent, so walk it with
+    // compile-time indices to keep the array in registers
+    float bary[D + 2];
+#pragma unroll
+    for (int k = 0; k < D + 2; k++) bary[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= D; k++) {
+        const float v = (el[k] - rem0[k]) * invdplus1;
+        const int p = D - (int)rank[k];
+#pragma unroll
+        for (int q = 0; q <= D; q++) {
+            if (q == p) { bary[q] += v; bary[q + 1] -= v; }
+        }
+    }
+    bary[0] += 1.0f + bary[D + 1];
+    // vertices (:266-275)
+#pragma unroll
+    for (int r = 0; r <= D; r++) {
+        Key8 key;
+#pragma unroll
+        for (int k = 0; k < 8; k++) key.k[k] = 0;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const int rk = (int)rank[k];
+            const int canon = rk <= D - r ? r : r - (D + 1);
+            key.k[k] = (short)(rem0[k] + (float)canon);
+        }
+        key.k[7] = (short)frame;
+        const unsigned slot = hash_insert(L.state, L.tkeys, L.cap_mask, L.counters, key);
+        if (real) {
+            L.offsets[gp * (D + 1) + r] = (int)slot;
+            L.bary[gp * (D + 1) + r] = bary[r];
+        }
+    }
+}
+
+void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s) {
+    const long long total = (long long)L.Npad * L.n_frames;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (L.d) {
+        case 1: lattice_points_kernel<1><<<grid, block, 0, s>>>(L, fs); break;
+        case 2: lattice_points_kernel<2><<<grid, block, 0, s>>>(L, fs); break;
+        case 3: lattice_points_kernel<3><<<grid, block, 0, s>>>(L, fs); break;
+        case 4: lattice_points_kernel<4><<<grid, block, 0, s>>>(L, fs); break;
+        case 5: lattice_points_kernel<5><<<grid, block, 0, s>>>(L, fs); break;
+        case 6: lattice_points_kernel<6><<<grid, block, 0, s>>>(L, fs); break;
+        case 7: lattice_points_kernel<7><<<grid, block, 0, s>>>(L, fs); break;
+        default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compaction: filled slots -> dense vertex ids (arbitrary order), compact key array
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+lattice_compact_kernel(LatticeDev L) {
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot > L.cap_mask) return;
+    if (L.state[slot] == ST_FILLED) {
+        const int id = atomicAdd(L.counters + 0, 1);
+        L.slot_to_id[slot] = id;
+        if ((unsigned)id < (unsigned)L.m_bound) {
+            L.vkeys[2 * (size_t)id] = L.tkeys[2 * (size_t)slot];
+            L.vkeys[2 * (size_t)id + 1] = L.tkeys[2 * (size_t)slot + 1];
+        }
+    }
+}
+
+// offsets: slot -> vertex id; sort keys / payloads for the stable vertex-major ordering
+__global__ void __launch_bounds__(256)
+lattice_remap_kernel(LatticeDev L, unsigned* __restrict__ sort_keys, unsigned* __restrict__ sort_vals, long long n_entries) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    const int id = L.slot_to_id[L.offsets[e]];
+    L.offsets[e] = id;
+    sort_keys[e] = (unsigned)id;
+    sort_vals[e] = (unsigned)e;
+}
+
+// blur neighbours (permutohedral.cpp:296-318).  For axis j == d the +-d write of the reference
+// lands on the coordinate that the d-length key ignores.
+__global__ void __launch_bounds__(256)
+lattice_neighbours_kernel(LatticeDev L) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int d = L.d;
+    if (gid >= (long long)M * (d + 1)) return;
+    const int j = (int)(gid / M);
+    const int id = (int)(gid - (long long)j * M);
+    Key8 key;
+    const unsigned long long* src = L.vkeys + 2 * (size_t)id;
+    reinterpret_cast<unsigned long long*>(key.k)[0] = src[0];
+    reinterpret_cast<unsigned long long*>(key.k)[1] = src[1];
+    Key8 n1 = key, n2 = key;
+    for (int k = 0; k < d; k++) { n1.k[k] = (short)(key.k[k] - 1); n2.k[k] = (short)(key.k[k] + 1); }
+    if (j < d) { n1.k[j] = (short)(key.k[j] + d); n2.k[j] = (short)(key.k[j] - d); }
+    const int s1 = hash_lookup(L.state, L.tkeys, L.cap_mask, n1);
+    const int s2 = hash_lookup(L.state, L.tkeys, L.cap_mask, n2);
+    L.nb1[(size_t)j * L.m_bound + id] = s1 < 0 ? -1 : L.slot_to_id[s1];
+    L.nb2[(size_t)j * L.m_bound + id] = s2 < 0 ? -1 : L.slot_to_id[s2];
+}
+
+// CSR over the sorted entries: point index, barycentric weight, per-vertex [start, end)
+__global__ void __launch_bounds__(256)
+lattice_csr_kernel(LatticeDev L, const unsigned* __restrict__ keys_sorted, const unsigned* __restrict__ vals_sorted,
+                   long long n_entries) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_entries) return;
+    const unsigned e = vals_sorted[k];
+    const unsigned key = keys_sorted[k];
+    L.csr_pix[k] = e / (unsigned)(L.d + 1);
+    L.csr_w[k] = L.bary[e];
+    if (k == 0 || keys_sorted[k - 1] != key) L.vstart[key] = (unsigned)k;
+    if (k == n_entries - 1 || keys_sorted[k + 1] != key) L.vend[key] = (unsigned)(k + 1);
+}
+
+void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
+    const unsigned cap = L.cap_mask + 1;
+    lattice_compact_kernel<<<dim3((cap + 255) / 256), dim3(256), 0, s>>>(L);
+    lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
+    const long long nb_threads = (long long)L.m_bound * (L.d + 1);
+    lattice_neighbours_kernel<<<dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, s>>>(L);
+    // stable radix sort by vertex id: equal keys keep ascending entry (= point) order
+    size_t temp = sb.temp_bytes;
+    (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
+                                    (unsigned)sb.key_bits, s);
+    lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+}
+
+size_t sort_temp_bytes(long long n_entries, int key_bits) {
+    size_t temp = 0;
+    unsigned* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t)n_entries, 0, (unsigned)key_bits, (hipStream_t)0);
+    return temp;
+}
+
+// norm values gathered into CSR order once the normaliser exists
+__global__ void __launch_bounds__(256)
+csr_norm_kernel(const unsigned* __restrict__ csr_pix, const float* __restrict__ norm, float* __restrict__ csr_nrm, long long n_entries) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_entries) csr_nrm[k] = norm[csr_pix[k]];
+}
+
+void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
+    csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pix, L.norm, L.csr_nrm, n_entries);
+}
+
+// ---------------------------------------------------------------------------------------------
+// splat as an ordered gather: one lane per (vertex, class) chain.
+//   values[v][c] = sum over the vertex's entries, ascending point index, of fl(w * in[p][c])
+//   with in[p][c] = fl(Q[p][c] * norm[p]) when `scaled` (DenseKernel::filter, pairwise.cpp:66)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>  // 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
+__global__ void __launch_bounds__(256)
+splat_gather_kernel(LatticeDev L, ValueView src, int C, float* __restrict__ values) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    if (gid >= (long long)M * C) return;
+    const int v = (int)(gid / C), c = (int)(gid - (long long)v * C);
+    const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+    float acc = 0.0f;
+    for (unsigned k = k0; k < k1; k++) {
+        const float w = L.csr_w[k];
+        float x;
+        if (MODE == 2) {
+            x = 1.0f;
+        } else {
+            const unsigned p = L.csr_pix[k];
+            x = src.at(p, c, C, L.N);
+            if (MODE == 1) x = x * L.csr_nrm[k];
+        }
+        const float prod = w * x;
+        acc += prod;
+    }
+    values[gid] = acc;
+}
+
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
+    const long long total = (long long)L.m_bound * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (mode == 0) splat_gather_kernel<0><<<grid, block, 0, s>>>(L, src, C, values);
+    else if (mode == 1) splat_gather_kernel<1><<<grid, block, 0, s>>>(L, src, C, values);
+    else splat_gather_kernel<2><<<grid, block, 0, s>>>(L, src, C, values);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blur along one lattice axis (permutohedral.cpp:556-569 / :496-510)
+// ---------------------------------------------------------------------------------------------
+template <bool SEQ>
+__global__ void __launch_bounds__(256)
+blur_kernel(LatticeDev L, int axis, int C, const float* __restrict__ old_v, float* __restrict__ new_v) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    if (gid >= (long long)M * C) return;
+    const int v = (int)(gid / C), c = (int)(gid - (long long)v * C);
+    const int n1 = L.nb1[(size_t)axis * L.m_bound + v], n2 = L.nb2[(size_t)axis * L.m_bound + v];
+    const float a = n1 >= 0 ? old_v[(size_t)n1 * C + c] : 0.0f;
+    const float b = n2 >= 0 ? old_v[(size_t)n2 * C + c] : 0.0f;
+    const float o = old_v[gid];
+    if (SEQ) {
+        new_v[gid] = (float)((double)o + 0.5 * (double)(a + b));  // seqCompute :505
+    } else {
+        const float sum = a + b;
+        const float h = 0.5f * sum;
+        new_v[gid] = o + h;                                        // sseCompute :566
+    }
+}
+
+// runs the d+1 axis passes; returns the buffer that holds the result
+float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s) {
+    const long long total = (long long)L.m_bound * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    float *cur = a, *nxt = b;
+    for (int t = 0; t <= L.d; t++) {
+        const int axis = reverse ? L.d - t : t;
+        if (seq) blur_kernel<true><<<grid, block, 0, s>>>(L, axis, C, cur, nxt);
+        else blur_kernel<false><<<grid, block, 0, s>>>(L, axis, C, cur, nxt);
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    return cur;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slice (permutohedral.cpp:574-584 / :515-524), one thread per (point, class)
+//   OUT_MODE 0: out[p][c] = sliced                      (plain filter, rvseg_lattice_filter)
+//   OUT_MODE 1: norm[p]   = 1/sqrt(sliced + 1e-20)      (normaliser, pairwise.cpp:55-56; C == 1)
+//   OUT_MODE 2: tmp[p][c] = tmp[p][c] - (-w) * (sliced * norm[p])   (filter + Potts + inference)
+// ---------------------------------------------------------------------------------------------
+template <bool SEQ, int OUT_MODE>
+__global__ void __launch_bounds__(256)
+slice_kernel(LatticeDev L, int C, const float* __restrict__ values, float alpha, float neg_w, float* __restrict__ out,
+             long long n_points) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_points * C) return;
+    const long long p = gid / C;
+    const int c = (int)(gid - p * C);
+    const int dp1 = L.d + 1;
+    float acc = 0.0f;
+    for (int j = 0; j < dp1; j++) {
+        const int o = L.offsets[p * dp1 + j];
+        const float bw = L.bary[p * dp1 + j];
+        const float val = values[(size_t)o * C + c];
+        if (SEQ) {
+            const float t = bw * val;
+            const float u = t * alpha;
+            acc += u;
+        } else {
+            const float w = bw * alpha;
+            const float prod = w * val;
+            acc += prod;
+        }
+    }
+    if (OUT_MODE == 0) {
+        out[gid] = acc;
+    } else if (OUT_MODE == 1) {
+        out[gid] = (float)(1.0 / sqrt((double)acc + 1e-20));
+    } else {
+        const float t = acc * L.norm[p];   // out = out*norm_.asDiagonal(), pairwise.cpp:79
+        const float m = neg_w * t;         // out = -w_*Q, labelcompatibility.cpp:47
+        out[gid] = out[gid] - m;           // tmp1 -= tmp2, densecrf.cpp:126
+    }
+}
+
+void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
+                  long long n_points, hipStream_t s) {
+    const float alpha = 1.0f / (1 + powf(2, (float)-L.d));  // permutohedral.cpp:571
+    const long long total = n_points * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define RV_SLICE(SEQ, OM) slice_kernel<SEQ, OM><<<grid, block, 0, s>>>(L, C, values, alpha, neg_w, out, n_points)
+    if (seq) {
+        if (out_mode == 0) RV_SLICE(true, 0); else if (out_mode == 1) RV_SLICE(true, 1); else RV_SLICE(true, 2);
+    } else {
+        if (out_mode == 0) RV_SLICE(false, 0); else if (out_mode == 1) RV_SLICE(false, 1); else RV_SLICE(false, 2);
+    }
+#undef RV_SLICE
+}
+
+// ---------------------------------------------------------------------------------------------
+// tmp = -U (densecrf.cpp:123) and expAndNormalize (densecrf.cpp:98-106)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+neg_unary_kernel(ValueView unary, int negate, int C, int N, float* __restrict__ tmp, long long n_points) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_points * C) return;
+    const long long p = gid / C;
+    const int c = (int)(gid - p * C);
+    const float u = unary.at((unsigned)p, c, C, N);
+    tmp[gid] = negate ? -u : u;
+}
+
+void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s) {
+    const long long total = n_points * C;
+    neg_unary_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(unary, negate ? 1 : 0, C, N, tmp, n_points);
+}
+
+__global__ void __launch_bounds__(256)
+softmax_kernel(const float* __restrict__ tmp, int C, int N, ValueView q, long long n_points) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_points) return;
+    const float* b = tmp + p * C;
+    float mx = b[0];
+    for (int c = 1; c < C; c++) { const float v = b[c]; if (v > mx) mx = v; }
+    float sum = 0.0f;
+    for (int c = 0; c < C; c++) {
+        const float e = exp_f32_dev(b[c] - mx);
+        q.ref((unsigned)p, c, C, N) = e;
+        sum += e;
+    }
+    for (int c = 0; c < C; c++) {
+        float& r = q.ref((unsigned)p, c, C, N);
+        r = r / sum;
+    }
+}
+
+void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {
+    softmax_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(tmp, C, N, q, n_points);
+}
+
+__global__ void __launch_bounds__(256)
+fill_int_kernel(int* p, int v, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void launch_fill_int(int* p, int v, long long n, hipStream_t s) {
+    if (n <= 0) return;
+    fill_int_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(p, v, n);
+}
+
+}  // namespace rvseg

@@ -1,0 +1,80 @@
+// Device-side views and launch interface of the lattice / mean-field kernels (kernels_crf.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rvseg_internal.h"
+
+namespace rvseg {
+
+// Everything a lattice kernel needs, passed by value.
+struct LatticeDev {
+    int d;          // feature dimension (<= 7)
+    int N;          // points per frame
+    int Npad;       // N rounded up to a multiple of 4 (SSE block padding, permutohedral.cpp:196)
+    int n_frames;
+    unsigned cap_mask;  // hash capacity (all frames) - 1
+    int m_bound;        // capacity of the per-vertex arrays
+    float scale[8];     // diagonal of E, permutohedral.cpp:177-182
+    int* state;                  // per slot: EMPTY / LOCKED / FILLED
+    unsigned long long* tkeys;   // per slot: 8 x int16 key (d coordinates .. frame)
+    int* slot_to_id;
+    int* counters;               // [0] vertices M, [1] overflow flag, [2] filled slots
+    unsigned long long* vkeys;   // per vertex id: key
+    int* offsets;                // P x (d+1): slot, later vertex id
+    float* bary;                 // P x (d+1)
+    int *nb1, *nb2;              // (d+1) x m_bound blur neighbours (-1 = none)
+    unsigned* csr_pix;           // entries sorted by vertex, ascending point index inside a vertex
+    float* csr_w;                // barycentric weight of the entry
+    float* csr_nrm;              // norm[csr_pix] (available after the normaliser pass)
+    unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
+    float* norm;                 // per point, pairwise.cpp:55-56
+};
+
+// Where the lattice features come from.
+struct FeatureSource {
+    int mode;            // 0: feat array P x d; 1: frame mode (cloud + colours, d = 6)
+    const float* feat;
+    const float4* cloud;
+    const uint8_t* rgb;
+    float xyz_kernel, rgb_kernel;
+};
+
+// N x C values addressed either densely or inside the per-frame posterior layout
+// (frame stride sumC*N floats, layer offset N*prefixC).
+struct ValueView {
+    float* base;
+    size_t frame_stride;
+    size_t layer_off;
+    __host__ __device__ __forceinline__ size_t index(unsigned p, int c, int C, int N) const {
+        const unsigned frame = p / (unsigned)N;
+        const unsigned i = p - frame * (unsigned)N;
+        return (size_t)frame * frame_stride + layer_off + (size_t)i * C + c;
+    }
+    __device__ __forceinline__ float at(unsigned p, int c, int C, int N) const { return base[index(p, c, C, N)]; }
+    __device__ __forceinline__ float& ref(unsigned p, int c, int C, int N) const { return base[index(p, c, C, N)]; }
+};
+
+struct SortBuffers {
+    unsigned *keys_in, *keys_out, *vals_in, *vals_out;
+    void* temp;
+    size_t temp_bytes;
+    int key_bits;
+};
+
+void launch_fill_int(int* p, int v, long long n, hipStream_t s);
+void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s);
+void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s);
+size_t sort_temp_bytes(long long n_entries, int key_bits);
+void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
+// mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s);
+float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s);
+// out_mode 0: plain, 1: normaliser, 2: inference update (tmp -= (-w) * (sliced * norm))
+void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
+                  long long n_points, hipStream_t s);
+void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);
+void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
+
+}  // namespace rvseg

@@ -1,16 +1,399 @@
-// placeholder: CRF pipeline (filled in next)
+// CRF orchestration: lattice construction, normaliser, mean-field loop; the C-ABI entry points
+// rvseg_crf_infer / rvseg_crf_infer_multi / rvseg_lattice_build / rvseg_lattice_filter and the
+// per-frame CRF stage of the frame pipeline.
+#include <cmath>
+#include <cstring>
+
+#include "rvseg_crf.h"
 #include "rvseg_pipeline.h"
+
 namespace rvseg {
-void crf_state_free(Pipeline*) {}
-rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline*, int, const uint8_t*, const float*, float*, int8_t*, hipStream_t) {
-    ctx->err = "dense CRF not implemented yet";
-    return RVSEG_ERR_INVALID_ARG;
+
+struct LatticeBufs {
+    DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pix, csr_w, csr_nrm, vstart, vend, norm;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp;
+    LatticeDev dev{};
+    SortBuffers sb{};
+    long long n_entries = 0, n_points = 0;
+    bool built = false;
+};
+
+struct CrfState {
+    std::vector<LatticeBufs> lat;  // one per pairwise kernel
+    DevBuf val_a, val_b, tmp, q, unary, feat, labels;
+    int* h_counters = nullptr;     // pinned: [0] M, [1] overflow, [2] filled of the last build
+    hipEvent_t counters_ev = nullptr;
+    bool counters_pending = false;
+};
+
+static CrfState* crf_state(Pipeline* im) {
+    if (!im->crf) {
+        im->crf = new CrfState();
+        (void)hipHostMalloc((void**)&im->crf->h_counters, 4 * sizeof(int), hipHostMallocDefault);
+        (void)hipEventCreateWithFlags(&im->crf->counters_ev, hipEventDisableTiming);
+    }
+    return im->crf;
 }
+
+static void lattice_free(LatticeBufs& b) {
+    DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
+                     &b.csr_pix, &b.csr_w, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
+                     &b.vals_out, &b.sort_temp};
+    for (DevBuf* x : all) dev_free(*x);
+}
+
+void crf_state_free(Pipeline* im) {
+    if (!im->crf) return;
+    for (auto& l : im->crf->lat) lattice_free(l);
+    DevBuf* all[] = {&im->crf->val_a, &im->crf->val_b, &im->crf->tmp, &im->crf->q, &im->crf->unary, &im->crf->feat, &im->crf->labels};
+    for (DevBuf* x : all) dev_free(*x);
+    if (im->crf->h_counters) (void)hipHostFree(im->crf->h_counters);
+    if (im->crf->counters_ev) (void)hipEventDestroy(im->crf->counters_ev);
+    delete im->crf;
+    im->crf = nullptr;
+}
+
+static int ceil_log2(unsigned long long v) {
+    int b = 0;
+    while ((1ull << b) < v) b++;
+    return b;
+}
+
+// per-frame hash capacity: params.lattice_capacity_log2 > 0 as given; 0 = 2^18; < 0 or `safe` =
+// enough for every point to own d+1 private vertices at load factor 1/2
+static int capacity_log2_per_frame(const rvseg_ctx* ctx, int Npad, int d, bool safe) {
+    const int safe_log2 = ceil_log2(2ull * (unsigned long long)Npad * (d + 1));
+    int want = ctx->params.lattice_capacity_log2;
+    if (safe || want < 0) return safe_log2;
+    if (want == 0) want = 18;
+    return want < safe_log2 ? want : safe_log2;
+}
+
+static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe) {
+    if (d < 1 || d > 7) { ctx->err = "feature dimension must be in [1,7]"; return RVSEG_ERR_INVALID_ARG; }
+    if (n_frames > 32767) { ctx->err = "too many frames per chunk"; return RVSEG_ERR_INVALID_ARG; }
+    const int Npad = (N + 3) / 4 * 4;
+    const int cap_log2 = capacity_log2_per_frame(ctx, Npad, d, safe) + ceil_log2((unsigned long long)n_frames);
+    if (cap_log2 > 31) { ctx->err = "lattice hash capacity too large"; return RVSEG_ERR_CAPACITY; }
+    const unsigned long long cap = 1ull << cap_log2;
+    const unsigned long long worst = (unsigned long long)Npad * n_frames * (d + 1);
+    const unsigned long long m_bound = std::min<unsigned long long>(cap / 2 + 2, worst);
+    const long long P = (long long)N * n_frames;
+    const long long E = P * (d + 1);
+    if (E >= (1ll << 32) || m_bound >= (1ull << 31)) { ctx->err = "too many lattice entries for 32-bit indices"; return RVSEG_ERR_CAPACITY; }
+    rvseg_status st;
+#define RV_RES(buf, bytes) if ((st = dev_reserve(ctx, buf, (size_t)(bytes))) != RVSEG_OK) return st
+    RV_RES(b.state, cap * 4);
+    RV_RES(b.tkeys, cap * 16);
+    RV_RES(b.slot_to_id, cap * 4);
+    RV_RES(b.counters, 16);
+    RV_RES(b.vkeys, m_bound * 16);
+    RV_RES(b.offsets, E * 4);
+    RV_RES(b.bary, E * 4);
+    RV_RES(b.nb1, m_bound * (d + 1) * 4);
+    RV_RES(b.nb2, m_bound * (d + 1) * 4);
+    RV_RES(b.csr_pix, E * 4);
+    RV_RES(b.csr_w, E * 4);
+    RV_RES(b.csr_nrm, E * 4);
+    RV_RES(b.vstart, m_bound * 4);
+    RV_RES(b.vend, m_bound * 4);
+    RV_RES(b.norm, P * 4);
+    RV_RES(b.keys_in, E * 4);
+    RV_RES(b.keys_out, E * 4);
+    RV_RES(b.vals_in, E * 4);
+    RV_RES(b.vals_out, E * 4);
+    const int key_bits = std::max(1, ceil_log2(m_bound));
+    const size_t temp = sort_temp_bytes(E, key_bits);
+    RV_RES(b.sort_temp, temp);
+#undef RV_RES
+    LatticeDev& L = b.dev;
+    L.d = d; L.N = N; L.Npad = Npad; L.n_frames = n_frames;
+    L.cap_mask = (unsigned)(cap - 1);
+    L.m_bound = (int)m_bound;
+    // diagonal of E (permutohedral.cpp:177-182): float inv_std_dev; scale = 1/sqrt((i+2)(i+1)) * inv_std_dev
+    const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (d + 1));
+    for (int i = 0; i < 8; i++) L.scale[i] = i < d ? (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * inv_std_dev) : 0.f;
+    L.state = b.state.as<int>(); L.tkeys = b.tkeys.as<unsigned long long>(); L.slot_to_id = b.slot_to_id.as<int>();
+    L.counters = b.counters.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
+    L.offsets = b.offsets.as<int>(); L.bary = b.bary.as<float>();
+    L.nb1 = b.nb1.as<int>(); L.nb2 = b.nb2.as<int>();
+    L.csr_pix = b.csr_pix.as<unsigned>(); L.csr_w = b.csr_w.as<float>(); L.csr_nrm = b.csr_nrm.as<float>();
+    L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.norm = b.norm.as<float>();
+    b.sb.keys_in = b.keys_in.as<unsigned>(); b.sb.keys_out = b.keys_out.as<unsigned>();
+    b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
+    b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
+    b.n_entries = E; b.n_points = P;
+    b.built = false;
+    return RVSEG_OK;
+}
+
+static rvseg_status values_reserve(rvseg_ctx* ctx, CrfState* cs, long long m_bound, int C) {
+    rvseg_status st;
+    if ((st = dev_reserve(ctx, cs->val_a, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, cs->val_b, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
+    return RVSEG_OK;
+}
+
+// Permutohedral::init + the normaliser of DenseKernel::initLattice (pairwise.cpp:40-56)
+static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, const FeatureSource& fs, hipStream_t s) {
+    const LatticeDev& L = b.dev;
+    RV_HIP(ctx, hipMemsetAsync(L.state, 0xFF, ((size_t)L.cap_mask + 1) * 4, s));
+    RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
+    RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
+    RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
+    launch_lattice_points(L, fs, s);
+    launch_lattice_finish(L, b.sb, b.n_entries, s);
+    rvseg_status st = values_reserve(ctx, cs, L.m_bound, 1);
+    if (st != RVSEG_OK) return st;
+    // norm = lattice.compute(ones) through seqCompute (1 row), then 1/sqrt(norm + 1e-20)
+    ValueView none{nullptr, 0, 0};
+    launch_splat(L, none, 1, 2, cs->val_a.as<float>(), s);
+    float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+    launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
+    launch_csr_norm(L, b.n_entries, s);
+    RV_HIP(ctx, hipGetLastError());
+    b.built = true;
+    return RVSEG_OK;
+}
+
+// synchronous read of the build counters (host entry points)
+static rvseg_status lattice_counters(rvseg_ctx* ctx, CrfState* cs, const LatticeBufs& b, hipStream_t s, int out[3]) {
+    RV_HIP(ctx, hipMemcpyAsync(cs->h_counters, b.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipStreamSynchronize(s));
+    out[0] = cs->h_counters[0]; out[1] = cs->h_counters[1]; out[2] = cs->h_counters[2];
+    return RVSEG_OK;
+}
+
+// DenseKernel::filter + PottsCompatibility::apply folded into tmp (pairwise.cpp:63-80,173-178)
+static void filter_into(const LatticeBufs& b, CrfState* cs, const ValueView& Q, int C, float w, float* tmp, hipStream_t s) {
+    const bool seq = C <= 2;  // Permutohedral::compute dispatch, permutohedral.cpp:600-603
+    launch_splat(b.dev, Q, C, 1, cs->val_a.as<float>(), s);
+    float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+    launch_slice(b.dev, C, seq, 2, blurred, -w, tmp, b.n_points, s);
+}
+
+// DenseCRF::inference (densecrf.cpp:115-131)
+static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, const float* ws, const ValueView& unary,
+                               bool unary_is_energy, int C, int N, long long n_points, int iterations,
+                               const ValueView& Q, hipStream_t s) {
+    rvseg_status st;
+    if ((st = dev_reserve(ctx, cs->tmp, (size_t)n_points * C * 4)) != RVSEG_OK) return st;
+    long long mb = 0;
+    for (int k = 0; k < n_kernels; k++) mb = std::max<long long>(mb, cs->lat[k].dev.m_bound);
+    if ((st = values_reserve(ctx, cs, mb, C)) != RVSEG_OK) return st;
+    float* tmp = cs->tmp.as<float>();
+    launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
+    launch_softmax(tmp, C, N, Q, n_points, s);
+    for (int it = 0; it < iterations; it++) {
+        launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
+        for (int k = 0; k < n_kernels; k++) filter_into(cs->lat[k], cs, Q, C, ws[k], tmp, s);
+        launch_softmax(tmp, C, N, Q, n_points, s);
+    }
+    RV_HIP(ctx, hipGetLastError());
+    return RVSEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame CRF stage of the frame pipeline
+// ---------------------------------------------------------------------------------------------
+rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, const float* d_post,
+                        float* d_marg, int8_t* d_labels, hipStream_t s) {
+    CrfState* cs = crf_state(im);
+    const FrameGeom& g = im->geom;
+    const rvseg_params& p = ctx->params;
+    const DeviceForest& f = ctx->forest;
+    const int N = g.W * g.H;
+    rvseg_status st;
+    // deferred overflow report of the previous asynchronous call
+    if (cs->counters_pending) {
+        RV_HIP(ctx, hipEventSynchronize(cs->counters_ev));
+        cs->counters_pending = false;
+        if (cs->h_counters[1]) {
+            ctx->err = "lattice hash table overflowed in the previous call (raise params.lattice_capacity_log2 or use -1)";
+            return RVSEG_ERR_CAPACITY;
+        }
+    }
+    if (cs->lat.size() < 1) cs->lat.resize(1);
+    LatticeBufs& lb = cs->lat[0];
+    if ((st = lattice_prepare(ctx, lb, 6, N, n, false)) != RVSEG_OK) return st;
+    FeatureSource fs{};
+    fs.mode = 1; fs.cloud = im->cloud.as<float4>(); fs.rgb = d_rgb;
+    fs.xyz_kernel = p.dcrf_xyz_kernel; fs.rgb_kernel = p.dcrf_rgb_kernel;
+    timer_mark(ctx, "lattice_build", s);
+    if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpyAsync(cs->h_counters, lb.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipEventRecord(cs->counters_ev, s));
+    cs->counters_pending = true;
+
+    const size_t frame_stride = (size_t)N * f.sum_classes;
+    float* marg = d_marg;
+    if (!marg) {
+        if ((st = dev_reserve(ctx, cs->q, frame_stride * 4 * n)) != RVSEG_OK) return st;
+        marg = cs->q.as<float>();
+    }
+    timer_mark(ctx, "mean_field", s);
+    int prefix = 0;
+    const float w = p.dcrf_kernel_weight;
+    for (int l = 0; l < f.n_layers; l++) {
+        const int C = f.class_counts[l];
+        ValueView U{const_cast<float*>(d_post), frame_stride, (size_t)N * prefix};
+        ValueView Q{marg, frame_stride, (size_t)N * prefix};
+        // unary energy = -(log-posterior) (segmenter.cpp:642), so -U is the posterior itself
+        if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, s)) != RVSEG_OK) return st;
+        prefix += C;
+    }
+    if (d_labels) {
+        timer_mark(ctx, "labels", s);
+        size_t loff = 0;
+        for (int i = 0; i < n; i++) {
+            prefix = 0;
+            for (int l = 0; l < f.n_layers; l++) {
+                launch_labels(marg + (size_t)i * frame_stride + (size_t)N * prefix, (size_t)N, f.class_counts[l], p.label_mode,
+                              p.unknown_label[l], d_labels + loff, s);
+                loff += (size_t)N;
+                prefix += f.class_counts[l];
+            }
+        }
+    }
+    return RVSEG_OK;
+}
+
 }  // namespace rvseg
-extern "C" {
-#define NOT_YET(ctx) do { if (ctx) (ctx)->err = "not implemented yet"; return RVSEG_ERR_INVALID_ARG; } while (0)
-rvseg_status rvseg_crf_infer(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const float*, const float*, float, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
-rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t, int32_t, int32_t, const int32_t*, const float* const*, const float*, const float*, int32_t, float*, int8_t*, int32_t, int32_t) { NOT_YET(ctx); }
-rvseg_status rvseg_lattice_build(rvseg_ctx* ctx, const float*, int32_t, int32_t, int32_t*, float*, int16_t*, int32_t, int32_t*) { NOT_YET(ctx); }
-rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float*, int32_t, float*) { NOT_YET(ctx); }
+
+using namespace rvseg;
+
+static rvseg_status crf_enter(rvseg_ctx* ctx, Pipeline** im_out, CrfState** cs_out) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    if (!ctx->impl) {
+        // the CRF entry points do not need the frame tables; create a bare pipeline object
+        Pipeline* im = new Pipeline();
+        ctx->impl = reinterpret_cast<rvseg_ctx::Impl*>(im);
+        im->bare = true;
+    }
+    *im_out = reinterpret_cast<Pipeline*>(ctx->impl);
+    *cs_out = crf_state(*im_out);
+    return RVSEG_OK;
 }
+
+extern "C" {
+
+rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t N, int32_t C, int32_t n_kernels, const int32_t* ds,
+                                   const float* const* features, const float* ws, const float* unary_energy,
+                                   int32_t iterations, float* Q_out, int8_t* map_out, int32_t label_mode, int32_t unknown_label) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_enter(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (N <= 0 || C <= 0 || C > 64 || n_kernels < 0 || n_kernels > 8 || iterations < 0 || !unary_energy || !Q_out ||
+        (n_kernels > 0 && (!ds || !features || !ws)) || label_mode < 0 || label_mode > 3) {
+        ctx->err = "bad arguments";
+        return RVSEG_ERR_INVALID_ARG;
+    }
+    hipStream_t s = ctx->stream;
+    if ((int)cs->lat.size() < n_kernels) cs->lat.resize(n_kernels);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        bool overflow = false;
+        for (int k = 0; k < n_kernels && !overflow; k++) {
+            LatticeBufs& lb = cs->lat[k];
+            if ((st = lattice_prepare(ctx, lb, ds[k], N, 1, attempt == 1)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, cs->feat, (size_t)N * ds[k] * 4)) != RVSEG_OK) return st;
+            RV_HIP(ctx, hipMemcpyAsync(cs->feat.p, features[k], (size_t)N * ds[k] * 4, hipMemcpyHostToDevice, s));
+            FeatureSource fs{};
+            fs.mode = 0; fs.feat = cs->feat.as<float>();
+            if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
+            int cnt[3];
+            if ((st = lattice_counters(ctx, cs, lb, s, cnt)) != RVSEG_OK) return st;
+            overflow = cnt[1] != 0;
+        }
+        if (!overflow) break;
+        if (attempt == 1) { ctx->err = "lattice hash table overflow"; return RVSEG_ERR_CAPACITY; }
+    }
+    const size_t tot = (size_t)N * C;
+    if ((st = dev_reserve(ctx, cs->unary, tot * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, cs->q, tot * 4)) != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpyAsync(cs->unary.p, unary_energy, tot * 4, hipMemcpyHostToDevice, s));
+    ValueView U{cs->unary.as<float>(), tot, 0}, Q{cs->q.as<float>(), tot, 0};
+    timer_reset(ctx);
+    timer_mark(ctx, "mean_field", s);
+    if ((st = mean_field(ctx, cs, n_kernels, ws, U, true, C, N, N, iterations, Q, s)) != RVSEG_OK) return st;
+    timer_mark(ctx, "end", s);
+    RV_HIP(ctx, hipMemcpyAsync(Q_out, cs->q.p, tot * 4, hipMemcpyDeviceToHost, s));
+    if (map_out) {
+        if ((st = dev_reserve(ctx, cs->labels, (size_t)N)) != RVSEG_OK) return st;
+        launch_labels(cs->q.as<float>(), (size_t)N, C, label_mode, unknown_label, cs->labels.as<int8_t>(), s);
+        RV_HIP(ctx, hipMemcpyAsync(map_out, cs->labels.p, (size_t)N, hipMemcpyDeviceToHost, s));
+    }
+    RV_HIP(ctx, hipStreamSynchronize(s));
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_crf_infer(rvseg_ctx* ctx, int32_t N, int32_t C, int32_t d, const float* unary_energy,
+                             const float* features, float potts_w, int32_t iterations, float* Q_out, int8_t* map_out,
+                             int32_t label_mode, int32_t unknown_label) {
+    const float* feats[1] = {features};
+    return rvseg_crf_infer_multi(ctx, N, C, 1, &d, feats, &potts_w, unary_energy, iterations, Q_out, map_out, label_mode, unknown_label);
+}
+
+rvseg_status rvseg_lattice_build(rvseg_ctx* ctx, const float* features, int32_t N, int32_t d, int32_t* offsets_out,
+                                 float* bary_out, int16_t* keys_out, int32_t keys_capacity, int32_t* M_out) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_enter(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (!features || N <= 0 || !M_out) { ctx->err = "bad arguments"; return RVSEG_ERR_INVALID_ARG; }
+    hipStream_t s = ctx->stream;
+    if (cs->lat.size() < 1) cs->lat.resize(1);
+    LatticeBufs& lb = cs->lat[0];
+    int cnt[3] = {0, 0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((st = lattice_prepare(ctx, lb, d, N, 1, attempt == 1)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, cs->feat, (size_t)N * d * 4)) != RVSEG_OK) return st;
+        RV_HIP(ctx, hipMemcpyAsync(cs->feat.p, features, (size_t)N * d * 4, hipMemcpyHostToDevice, s));
+        FeatureSource fs{};
+        fs.mode = 0; fs.feat = cs->feat.as<float>();
+        if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
+        if ((st = lattice_counters(ctx, cs, lb, s, cnt)) != RVSEG_OK) return st;
+        if (!cnt[1]) break;
+        if (attempt == 1) { ctx->err = "lattice hash table overflow"; return RVSEG_ERR_CAPACITY; }
+    }
+    const int M = cnt[0];
+    *M_out = M;
+    const size_t E = (size_t)N * (d + 1);
+    if (offsets_out) RV_HIP(ctx, hipMemcpyAsync(offsets_out, lb.dev.offsets, E * 4, hipMemcpyDeviceToHost, s));
+    if (bary_out) RV_HIP(ctx, hipMemcpyAsync(bary_out, lb.dev.bary, E * 4, hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipStreamSynchronize(s));
+    if (keys_out) {
+        if (keys_capacity < M) { ctx->err = "keys_out too small"; return RVSEG_ERR_INVALID_ARG; }
+        std::vector<int16_t> k8((size_t)M * 8);
+        RV_HIP(ctx, hipMemcpy(k8.data(), lb.dev.vkeys, (size_t)M * 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i < M; i++)
+            for (int k = 0; k < d; k++) keys_out[(size_t)i * d + k] = k8[(size_t)i * 8 + k];
+    }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float* in, int32_t C, float* out) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_enter(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (cs->lat.empty() || !cs->lat[0].built || cs->lat[0].dev.n_frames != 1) { ctx->err = "no lattice built on this context"; return RVSEG_ERR_INVALID_ARG; }
+    if (!in || !out || C <= 0 || C > 64) { ctx->err = "bad arguments"; return RVSEG_ERR_INVALID_ARG; }
+    LatticeBufs& lb = cs->lat[0];
+    const int N = lb.dev.N;
+    hipStream_t s = ctx->stream;
+    const size_t tot = (size_t)N * C;
+    if ((st = dev_reserve(ctx, cs->q, tot * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, cs->tmp, tot * 4)) != RVSEG_OK) return st;
+    if ((st = values_reserve(ctx, cs, lb.dev.m_bound, C)) != RVSEG_OK) return st;
+    RV_HIP(ctx, hipMemcpyAsync(cs->q.p, in, tot * 4, hipMemcpyHostToDevice, s));
+    const bool seq = C <= 2;
+    ValueView V{cs->q.as<float>(), tot, 0};
+    launch_splat(lb.dev, V, C, 0, cs->val_a.as<float>(), s);
+    float* blurred = launch_blur(lb.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+    launch_slice(lb.dev, C, seq, 0, blurred, 0.f, cs->tmp.as<float>(), N, s);
+    RV_HIP(ctx, hipGetLastError());
+    RV_HIP(ctx, hipMemcpyAsync(out, cs->tmp.p, tot * 4, hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipStreamSynchronize(s));
+    return RVSEG_OK;
+}
+
+}  // extern "C"

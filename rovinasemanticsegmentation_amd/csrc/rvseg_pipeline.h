@@ -16,6 +16,7 @@ struct Pipeline {
     float* h_calibA = nullptr;  // pinned staging for the per-frame A = R*Kinv, t
     size_t h_calibA_bytes = 0;
     CrfState* crf = nullptr;
+    bool bare = false;  // created by a CRF entry point: frame tables not initialised yet
 };
 
 rvseg_status pipeline_init(rvseg_ctx* ctx);

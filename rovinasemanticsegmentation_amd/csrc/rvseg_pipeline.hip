@@ -36,7 +36,7 @@ static rvseg_status upload(rvseg_ctx* ctx, DevBuf& b, const void* src, size_t by
 }
 
 rvseg_status pipeline_init(rvseg_ctx* ctx) {
-    if (ctx->impl) return RVSEG_OK;
+    if (ctx->impl && !reinterpret_cast<Pipeline*>(ctx->impl)->bare) return RVSEG_OK;
     const rvseg_params& p = ctx->params;
     if (p.width % p.stride != 0 || p.height % p.stride != 0) {
         // the reference would scatter outside its low-res image (segmenter.cpp:357,370)
@@ -44,8 +44,9 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
         return RVSEG_ERR_INVALID_ARG;
     }
     if (p.patch_size_reduce > 16) { ctx->err = "patch_size_reduce > 16 is not supported"; return RVSEG_ERR_INVALID_ARG; }
-    Pipeline* im = new Pipeline();
+    Pipeline* im = ctx->impl ? reinterpret_cast<Pipeline*>(ctx->impl) : new Pipeline();
     ctx->impl = reinterpret_cast<rvseg_ctx::Impl*>(im);
+    im->bare = false;
     FrameGeom& g = im->geom;
     g.W = p.width; g.H = p.height; g.stride = p.stride;
     g.lw = p.width / p.stride; g.lh = p.height / p.stride;

@@ -1,0 +1,135 @@
+"""GPU parity of the permutohedral lattice and the DenseCRF mean-field through the C ABI against
+the CPU oracle.  Bar: lattice structure and barycentric weights bit-exact (up to vertex
+renumbering, which no result depends on); filter outputs and marginals bit-exact, which implies
+the 1e-4 marginal tolerance of the north star; MAP labels identical."""
+import os
+
+import numpy as np
+import pytest
+
+from rovinasemanticsegmentation_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north-star tolerance on CRF marginals (we assert bit-exactness, which is stronger)
+
+
+def _features(seed, N, d, spread=4.0):
+    rng = np.random.default_rng(seed)
+    return (rng.random((N, d)) * spread - spread / 3).astype(np.float32)
+
+
+@pytest.mark.parametrize("d,N", [(2, 4000), (5, 4000), (6, 4000), (6, 4003), (3, 10), (1, 64), (7, 512)])
+def test_lattice_structure_matches_oracle(gpu_ctx_factory, oracle, d, N):
+    F = _features(d * 100 + N, N, d)
+    lat = oracle.Lattice(F)
+    ctx = gpu_ctx_factory()
+    off, bary, keys, M = ctx.lattice_build(F)
+    assert M == lat.M
+    assert np.array_equal(bary, lat.barycentric)
+    got_keys = keys[off]            # N x (d+1) x d
+    want_keys = lat.keys[lat.offset]
+    assert np.array_equal(got_keys, want_keys)
+    assert sorted(map(tuple, keys.tolist())) == sorted(map(tuple, lat.keys.tolist()))
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 9])
+def test_lattice_filter_bit_exact(gpu_ctx_factory, oracle, C):
+    N, d = 6000, 5
+    F = _features(7, N, d, spread=3.0)
+    V = np.random.default_rng(C).random((N, C)).astype(np.float32)
+    want = oracle.Lattice(F).compute(V)
+    ctx = gpu_ctx_factory()
+    ctx.lattice_build(F)
+    got = ctx.lattice_filter(V)
+    assert np.abs(got - want).max() <= TOL
+    assert np.array_equal(got, want)
+
+
+def test_lattice_filter_skewed_vertices(gpu_ctx_factory, oracle):
+    # nearly all points fall into one simplex: one very long ordered chain per class
+    rng = np.random.default_rng(0)
+    N, d, C = 40000, 6, 9
+    F = (rng.random((N, d)) * 0.05).astype(np.float32)
+    V = rng.random((N, C)).astype(np.float32)
+    lat = oracle.Lattice(F)
+    assert lat.M < 40
+    ctx = gpu_ctx_factory()
+    ctx.lattice_build(F)
+    assert np.array_equal(ctx.lattice_filter(V), lat.compute(V))
+
+
+def test_hash_overflow_falls_back_to_safe_capacity(gpu_ctx_factory, oracle):
+    # 2^4 slots cannot hold the lattice: the host entry points rebuild with the safe capacity
+    F = _features(3, 2000, 3, spread=40.0)
+    lat = oracle.Lattice(F)
+    ctx = gpu_ctx_factory(lattice_capacity_log2=4)
+    off, bary, keys, M = ctx.lattice_build(F)
+    assert M == lat.M and np.array_equal(keys[off], lat.keys[lat.offset])
+
+
+@pytest.mark.parametrize("C,d", [(9, 6), (2, 3), (21, 5)])
+def test_crf_infer_bit_exact(gpu_ctx_factory, oracle, C, d):
+    rng = np.random.default_rng(C)
+    N = 8000
+    F = _features(11, N, d, spread=2.5)
+    U = (rng.random((N, C)) * 5).astype(np.float32)
+    want = oracle.crf_inference(U, F, 10.0, 5)
+    ctx = gpu_ctx_factory()
+    Q, mp = ctx.crf_infer(U, F, 10.0, 5)
+    assert np.abs(Q - want).max() <= TOL
+    assert np.array_equal(Q, want)
+    assert np.array_equal(mp, oracle.labels(want, C, 3))
+    # zero iterations and zero weight reduce to the softmax of -U
+    Q0, _ = ctx.crf_infer(U, F, 10.0, 0)
+    assert np.array_equal(Q0, oracle.exp_and_normalize(-U))
+
+
+def test_crf_label_rule_with_unknown(gpu_ctx_factory, oracle):
+    rng = np.random.default_rng(5)
+    N, C = 4000, 9
+    F = _features(2, N, 6)
+    U = (rng.random((N, C)) * 0.7).astype(np.float32)  # flat marginals: many below 2/C
+    ctx = gpu_ctx_factory()
+    Q, mp = ctx.crf_infer(U, F, 1.0, 2, label_mode=1, unknown_label=8)
+    want = oracle.labels(oracle.crf_inference(U, F, 1.0, 2), C, 1, unknown=8)
+    assert np.array_equal(mp, want)
+    assert (mp == 8).any()
+
+
+def test_dense_inference_example_on_reference_ppm(gpu_ctx_factory, oracle, golden_dir):
+    import rovinasemanticsegmentation_amd as rv
+    from test_oracle_crf import dense_inference_inputs
+    im, lbl, U, W, H = dense_inference_inputs(golden_dir)
+    ctx = gpu_ctx_factory()
+    crf = rv.DenseCRF(ctx, W * H, 21)
+    crf.setUnaryEnergy(U)
+    crf.addPairwiseGaussian(W, H, 3, 3, 3.0)                       # dense_inference.cpp:94
+    crf.addPairwiseBilateral(W, H, 80, 80, 13, 13, 13, im, 10.0)   # dense_inference.cpp:101
+    Q, mp = crf.inference(5)
+    want = oracle.crf_inference_multi(U, [k[0] for k in crf.kernels], [3.0, 10.0], 5)
+    assert np.abs(Q - want).max() <= TOL
+    assert np.array_equal(Q, want)
+    z = np.load(os.path.join(golden_dir, "crf_im2_regression.npz"))
+    assert np.array_equal(mp, z["map"])
+
+
+def test_frames_with_crf_bit_exact(gpu_ctx_factory, oracle):
+    blob = synthetic.make_forest_bytes(seed=21, n_trees=4, leaves_per_tree=1024, max_depth=20)
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(3, holes=True)
+    calib = synthetic.make_calib()
+    kw = dict(use_dense_crf=1, dcrf_iterations=5, label_mode=1, max_batch=2)
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    p = oracle.default_params(dcrf_iterations=5)
+    for i in range(3):
+        post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[7, 8])
+        assert np.array_equal(out["posteriors"][i], post)
+        assert np.abs(out["marginals"][i] - marg).max() <= TOL
+        assert np.array_equal(out["marginals"][i], marg), i
+        assert np.array_equal(out["labels"][i].ravel(), lab)
+    # marginals are distributions
+    m = out["marginals"][0][: 640 * 480 * 8].reshape(-1, 8)
+    assert np.allclose(m.sum(1), 1, atol=1e-5)
