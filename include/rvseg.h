@@ -163,6 +163,11 @@ rvseg_status rvseg_lattice_build(rvseg_ctx *ctx, const float *features, int32_t 
                                  int32_t keys_capacity, int32_t *M_out);
 /* filter one value matrix (N x C) through the lattice last built on this ctx */
 rvseg_status rvseg_lattice_filter(rvseg_ctx *ctx, const float *in, int32_t C, float *out);
+/* blur neighbours of the lattice last built (permutohedral.cpp:296-318): n1_out / n2_out are
+ * (d+1) x M vertex ids (-1 = absent), in this ctx's vertex numbering.  Optional: the vertex-major
+ * entry order used by the ordered splat: csr_point (N*(d+1)), vstart / vend (M). */
+rvseg_status rvseg_lattice_neighbours(rvseg_ctx *ctx, int32_t *n1_out, int32_t *n2_out, uint32_t *csr_point,
+                                      uint32_t *vstart, uint32_t *vend);
 
 /* ---- timing of the last segment_frames / crf_infer call, measured with HIP events on the
  *      stream the kernels ran on.  names_out receives a ';'-separated list of stage names,

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rvseg_status_string", "rvseg_feature_length", "rvseg_forest_load", "rvseg_forest_load_mem",
     "rvseg_forest_info", "rvseg_forest_eval", "rvseg_extract_features", "rvseg_segment_frames",
     "rvseg_segment_frames_device", "rvseg_crf_infer", "rvseg_crf_infer_multi",
-    "rvseg_lattice_build", "rvseg_lattice_filter", "rvseg_last_timing",
+    "rvseg_lattice_build", "rvseg_lattice_filter", "rvseg_lattice_neighbours", "rvseg_last_timing",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
     L.rvseg_crf_infer_multi.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32]
     L.rvseg_lattice_build.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]
     L.rvseg_lattice_filter.argtypes = [vp, vp, i32, vp]
+    L.rvseg_lattice_neighbours.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rvseg_last_timing.argtypes = [vp, C.c_char_p, C.c_size_t, vp, i32]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library does not export it

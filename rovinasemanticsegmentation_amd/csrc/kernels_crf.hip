@@ -31,14 +31,21 @@ namespace rvseg {
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_EMPTY = -1, ST_LOCKED = -2, ST_FILLED = 0;
 
-struct Key8 { short k[8]; };  // d coordinates, then the frame index at k[7]; unused = 0
+// d coordinates, then the frame index at k[7]; unused = 0.  A union so that the short / word /
+// quad-word views alias legally (plain reinterpret_casts let the compiler drop the short stores).
+struct Key8 {
+    union {
+        short k[8];
+        unsigned w[4];
+        unsigned long long q[2];
+    };
+};
 
 __device__ __forceinline__ unsigned hash_key(const Key8& key) {
-    const unsigned* w = reinterpret_cast<const unsigned*>(key.k);
     unsigned h = 0x9E3779B9u;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        h ^= w[i];
+        h ^= key.w[i];
         h *= 0x85EBCA6Bu;
         h ^= h >> 15;
     }
@@ -46,7 +53,7 @@ __device__ __forceinline__ unsigned hash_key(const Key8& key) {
 }
 
 __device__ __forceinline__ bool key_equal_at(const unsigned long long* tkeys, unsigned slot, const Key8& key) {
-    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+    const unsigned long long* mine = key.q;
     // agent-scope loads: another CU may have written the key after this CU cached the line
     const unsigned long long a = __hip_atomic_load(tkeys + 2 * (size_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(tkeys + 2 * (size_t)slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -63,7 +70,7 @@ __device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* 
             int expected = ST_EMPTY;
             if (__hip_atomic_compare_exchange_strong(state + h, &expected, ST_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
-                const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+                const unsigned long long* mine = key.q;
                 __hip_atomic_store(tkeys + 2 * (size_t)h, mine[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(tkeys + 2 * (size_t)h + 1, mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(state + h, ST_FILLED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -85,7 +92,7 @@ __device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* 
 // read-only lookup (table complete, written by earlier kernels)
 __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long long* tkeys, unsigned mask, const Key8& key) {
     unsigned h = hash_key(key) & mask;
-    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(key.k);
+    const unsigned long long* mine = key.q;
     for (unsigned probes = 0; probes <= mask; probes++) {
         if (state[h] == ST_EMPTY) return -1;
         if (tkeys[2 * (size_t)h] == mine[0] && tkeys[2 * (size_t)h + 1] == mine[1]) return (int)h;
@@ -262,8 +269,8 @@ lattice_neighbours_kernel(LatticeDev L) {
     const int id = (int)(gid - (long long)j * M);
     Key8 key;
     const unsigned long long* src = L.vkeys + 2 * (size_t)id;
-    reinterpret_cast<unsigned long long*>(key.k)[0] = src[0];
-    reinterpret_cast<unsigned long long*>(key.k)[1] = src[1];
+    key.q[0] = src[0];
+    key.q[1] = src[1];
     Key8 n1 = key, n2 = key;
     for (int k = 0; k < d; k++) { n1.k[k] = (short)(key.k[k] - 1); n2.k[k] = (short)(key.k[k] + 1); }
     if (j < d) { n1.k[j] = (short)(key.k[j] + d); n2.k[j] = (short)(key.k[j] - d); }

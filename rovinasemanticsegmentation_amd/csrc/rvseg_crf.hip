@@ -371,6 +371,26 @@ rvseg_status rvseg_lattice_build(rvseg_ctx* ctx, const float* features, int32_t 
     return RVSEG_OK;
 }
 
+rvseg_status rvseg_lattice_neighbours(rvseg_ctx* ctx, int32_t* n1_out, int32_t* n2_out, uint32_t* csr_point,
+                                      uint32_t* vstart, uint32_t* vend) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_enter(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (cs->lat.empty() || !cs->lat[0].built || cs->lat[0].dev.n_frames != 1) { ctx->err = "no lattice built on this context"; return RVSEG_ERR_INVALID_ARG; }
+    LatticeBufs& lb = cs->lat[0];
+    int cnt[3];
+    if ((st = lattice_counters(ctx, cs, lb, ctx->stream, cnt)) != RVSEG_OK) return st;
+    const int M = cnt[0], d = lb.dev.d;
+    for (int j = 0; j <= d; j++) {
+        if (n1_out) RV_HIP(ctx, hipMemcpy(n1_out + (size_t)j * M, lb.dev.nb1 + (size_t)j * lb.dev.m_bound, (size_t)M * 4, hipMemcpyDeviceToHost));
+        if (n2_out) RV_HIP(ctx, hipMemcpy(n2_out + (size_t)j * M, lb.dev.nb2 + (size_t)j * lb.dev.m_bound, (size_t)M * 4, hipMemcpyDeviceToHost));
+    }
+    if (csr_point) RV_HIP(ctx, hipMemcpy(csr_point, lb.dev.csr_pix, (size_t)lb.n_entries * 4, hipMemcpyDeviceToHost));
+    if (vstart) RV_HIP(ctx, hipMemcpy(vstart, lb.dev.vstart, (size_t)M * 4, hipMemcpyDeviceToHost));
+    if (vend) RV_HIP(ctx, hipMemcpy(vend, lb.dev.vend, (size_t)M * 4, hipMemcpyDeviceToHost));
+    return RVSEG_OK;
+}
+
 rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float* in, int32_t C, float* out) {
     Pipeline* im; CrfState* cs;
     rvseg_status st = crf_enter(ctx, &im, &cs);

@@ -153,6 +153,15 @@ class Context:
         capi.check(self.h, self.L.rvseg_lattice_build(self.h, _ptr(F), N, d, _ptr(off), _ptr(bary), _ptr(keys), cap, C.byref(M)))
         return off, bary, keys[:M.value].copy(), M.value
 
+    def lattice_neighbours(self, M, d, N):
+        n1 = np.empty((d + 1, M), np.int32)
+        n2 = np.empty((d + 1, M), np.int32)
+        pix = np.empty(N * (d + 1), np.uint32)
+        vs = np.empty(M, np.uint32)
+        ve = np.empty(M, np.uint32)
+        capi.check(self.h, self.L.rvseg_lattice_neighbours(self.h, _ptr(n1), _ptr(n2), _ptr(pix), _ptr(vs), _ptr(ve)))
+        return n1, n2, pix, vs, ve
+
     def lattice_filter(self, values):
         V = np.ascontiguousarray(values, np.float32)
         out = np.empty_like(V)

@@ -53,7 +53,7 @@ def test_lattice_filter_skewed_vertices(gpu_ctx_factory, oracle):
     F = (rng.random((N, d)) * 0.05).astype(np.float32)
     V = rng.random((N, C)).astype(np.float32)
     lat = oracle.Lattice(F)
-    assert lat.M < 40
+    assert lat.M < 100
     ctx = gpu_ctx_factory()
     ctx.lattice_build(F)
     assert np.array_equal(ctx.lattice_filter(V), lat.compute(V))
