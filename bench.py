@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s of the RF + 5-iteration DenseCRF hot path at 640x480 RGB-D on MI355X.
+
+A "step" is one pass of the hot path over one batch of 64 synthetic 640x480 key frames
+(BASELINE.json configs[2], the HBM-roofline run; configs[1] -- a single frame -- is the same call
+with n = 1 and is reported as `latency_ms_single_frame`).  Inputs are resident in HBM before the
+timed region; every step writes CRF marginals and labels to HBM.  With --gpus N > 1 the driver
+starts one process per GPU (torch.distributed over RCCL): frames shard across ranks with no
+data-path collective except the final label gather to rank 0, i.e. weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+FRAMES_PER_STEP = 64
+CRF_ITERS = 5
+C_CLASSES = 9
+D_FEAT = 6
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+# Algorithmic HBM bytes per full-resolution pixel and LAUNCH GROUP (SURVEY.md 8d, C = 9, d = 6).
+# `launches` = how many times the stage runs per step.
+STAGE_BYTES_PER_PX = {
+    "prep": 5.0,                      # 3 B rgb + 2 B depth in
+    "window_map": 0.0, "normal_feature": 0.0,
+    "rf_frames": 0.0,                 # reads cached forest / Lab; its output is the low-res image
+    "upsample_pack": 4.0 * C_CLASSES,  # posteriors out
+    "lattice_build": 8.0 * (D_FEAT + 1) + 8.0 * (D_FEAT + 1) + 4,  # coefficients once + normaliser pass
+    "softmax": 4.0 * C_CLASSES * 2,   # read logits, write Q
+    "splat": 4.0 * C_CLASSES + 8.0 * (D_FEAT + 1),
+    "blur": 0.0,
+    "slice": 8.0 * (D_FEAT + 1) + 4.0 * C_CLASSES + 4,
+    "labels": 4.0 * C_CLASSES + 1,
+}
+PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.md 8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="key frames per step and GPU")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_frames, blob, rgb, depth, calib):
+    """The CPU oracle (a port of the reference structure, single thread like the reference's
+    inference path, src/segmenter.cpp:336-435) timed on this box's host cores."""
+    from oracle import oracle as O
+    forest = O.Forest(blob)
+    p = O.default_params(dcrf_iterations=CRF_ITERS)
+    O.segment_frame(p, forest, 0, rgb[0], depth[0], calib, label_mode=1, unknown=[8])  # warm caches / page in
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        O.segment_frame(p, forest, 0, rgb[i % len(rgb)], depth[i % len(depth)], calib, label_mode=1, unknown=[8])
+    dt = time.perf_counter() - t0
+    return {"value": n_frames * W * H / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 640x480 frames, RF (C=9) + 5-iter DenseCRF, oracle/rvseg_oracle.c, 1 thread"
+                      % n_frames,
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import rovinasemanticsegmentation_amd as rv
+    from rovinasemanticsegmentation_amd import synthetic
+
+    n = args.frames
+    N = W * H
+    blob = synthetic.make_forest_bytes(seed=7, n_trees=4, leaves_per_tree=1 << 14, max_depth=30,
+                                       single_classes=C_CLASSES, layer_classes=(8, 9))
+    # each rank owns different frames of the local map
+    rgb_h, depth_h = synthetic.make_batch(n, W, H, holes=False, start=rank * n)
+    calib = synthetic.make_calib(W, H)
+    d_rgb = torch.from_numpy(rgb_h).to(dev)
+    d_depth = torch.from_numpy(depth_h.view(np.int16)).to(dev)
+    d_marg = torch.empty((n, C_CLASSES * N), dtype=torch.float32, device=dev)
+    d_labels = torch.empty((n, N), dtype=torch.int8, device=dev)
+    gathered = [torch.empty_like(d_labels) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=CRF_ITERS, label_mode=rv.capi.LABEL_CRF,
+                     unknown_label=[8], max_batch=n, device=dev.index or 0,
+                     # the Segmenter kernel (xyz*0.5, rgb*4) yields ~300 lattice vertices per frame;
+                     # 2^12 slots per frame keep the per-vertex launches small (overflow is detected)
+                     lattice_capacity_log2=12)
+    ctx.forest_load(blob)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
+                                  d_labels.data_ptr(), stream.cuda_stream)
+        if world > 1:  # local-map label fusion: one gather to the fusion rank over xGMI
+            dist.gather(d_labels, gathered, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-stage durations of the LAST step, from HIP events recorded on the launch stream
+    stages = ctx.last_timing()
+    # single-frame latency (configs[1]) -- outside the timed region
+    lat = None
+    if rank == 0:
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.segment_frames_device(1, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
+                                      d_labels.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        lat = (time.perf_counter() - t1) / reps * 1e3
+        # overflow / async error check of the last call
+        ctx.segment_frames_device(1, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
+                                  d_labels.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        px_per_step = n * N
+        value = n_gpus * px_per_step * args.steps / dt / 1e6
+        # dominant stage and its roofline position
+        launches = {"softmax": CRF_ITERS + 1, "splat": CRF_ITERS, "blur": CRF_ITERS, "slice": CRF_ITERS}
+        dom = max(stages, key=stages.get) if stages else None
+        roof = None
+        if dom:
+            k = launches.get(dom, 1)
+            bytes_per_launch = STAGE_BYTES_PER_PX.get(dom, 0.0) * px_per_step
+            avg_ms = stages[dom] / k
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": k,
+                    "algorithmic_bytes_per_launch": bytes_per_launch}
+        out = {
+            "metric": "Mpix/s RF+5-iter DenseCRF @640x480 RGB-D", "value": round(value, 3), "unit": "Mpix/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic 640x480 RGB-D key frames per GPU, 4-tree forest "
+                                   "(2^14 leaves/tree, D=366, C=9), RF + 5-iter DenseCRF (d=6, Potts w=10), "
+                                   "marginals + labels written to HBM" % n,
+                       "frames_per_step_per_gpu": n, "label_gather": "rccl gather to rank 0" if world > 1 else "none"},
+            "roofline": roof,
+            "pipeline_hbm_frac": round(PIPELINE_BYTES_PER_PX * value * 1e6 / n_gpus / (HBM_PEAK_GBS * 1e9), 5),
+            "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
+            "latency_ms_single_frame": round(lat, 3) if lat else None,
+        }
+        if n_gpus == 1 and not args.no_cpu and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, blob, rgb_h, depth_h, calib)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -330,34 +330,90 @@ void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
 //   values[v][c] = sum over the vertex's entries, ascending point index, of fl(w * in[p][c])
 //   with in[p][c] = fl(Q[p][c] * norm[p]) when `scaled` (DenseKernel::filter, pairwise.cpp:66)
 // ---------------------------------------------------------------------------------------------
+// One wavefront per vertex.  Per tile of 64 list entries the lanes first form the 64 x C products
+// in parallel (coalesced reads of the CSR arrays, one gathered Q row per lane) and park them in
+// LDS; then lane c adds the tile's products of class c in list order -- the only part that has to
+// be sequential.  The next tile's loads are issued before the sequential phase so that their
+// latency hides behind the dependent adds.
+constexpr int SPLAT_CC = 16;  // classes per pass (LDS: 16 x 65 floats per wave)
+
 template <int MODE>  // 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 splat_gather_kernel(LatticeDev L, ValueView src, int C, float* __restrict__ values) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float prod[SPLAT_CC][68];  // 16-B aligned rows, 4-bank skew
+    const int v = blockIdx.x;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
-    if (gid >= (long long)M * C) return;
-    const int v = (int)(gid / C), c = (int)(gid - (long long)v * C);
+    if (v >= M) return;
+    const int lane = threadIdx.x;
     const unsigned k0 = L.vstart[v], k1 = L.vend[v];
-    float acc = 0.0f;
-    for (unsigned k = k0; k < k1; k++) {
-        const float w = L.csr_w[k];
-        float x;
-        if (MODE == 2) {
-            x = 1.0f;
-        } else {
-            const unsigned p = L.csr_pix[k];
-            x = src.at(p, c, C, L.N);
-            if (MODE == 1) x = x * L.csr_nrm[k];
+    for (int c0 = 0; c0 < C; c0 += SPLAT_CC) {
+        const int cc = C - c0 < SPLAT_CC ? C - c0 : SPLAT_CC;
+        float acc = 0.0f;
+        float x[SPLAT_CC];
+        float w = 0.f, nrm = 1.f;
+        // prefetch tile 0
+        {
+            const unsigned k = k0 + lane;
+            if (k < k1) {
+                w = L.csr_w[k];
+                if (MODE != 2) {
+                    const unsigned p = L.csr_pix[k];
+                    if (MODE == 1) nrm = L.csr_nrm[k];
+                    const size_t row = src.index(p, c0, C, L.N);
+#pragma unroll
+                    for (int c = 0; c < SPLAT_CC; c++) if (c < cc) x[c] = src.base[row + c];
+                }
+            }
         }
-        const float prod = w * x;
-        acc += prod;
+        for (unsigned base = k0; base < k1; base += 64) {
+            const unsigned n_valid = k1 - base < 64u ? k1 - base : 64u;
+            if ((unsigned)lane < n_valid) {
+#pragma unroll
+                for (int c = 0; c < SPLAT_CC; c++) {
+                    if (c < cc) {
+                        float xin = MODE == 2 ? 1.0f : x[c];
+                        if (MODE == 1) xin = xin * nrm;
+                        prod[c][lane] = w * xin;
+                    }
+                }
+            }
+            __syncthreads();
+            // issue the next tile's loads; they complete while the adds below run
+            {
+                const unsigned k = base + 64 + lane;
+                if (k < k1) {
+                    w = L.csr_w[k];
+                    if (MODE != 2) {
+                        const unsigned p = L.csr_pix[k];
+                        if (MODE == 1) nrm = L.csr_nrm[k];
+                        const size_t row = src.index(p, c0, C, L.N);
+#pragma unroll
+                        for (int c = 0; c < SPLAT_CC; c++) if (c < cc) x[c] = src.base[row + c];
+                    }
+                }
+            }
+            if (lane < cc) {
+                const float* pr = prod[lane];
+                if (n_valid == 64u) {
+                    // all 16 quad reads are issued before the first add: one LDS round trip per
+                    // tile instead of one per element; the adds stay strictly in list order
+                    float4 q[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+                } else {
+                    for (unsigned k = 0; k < n_valid; k++) acc += pr[k];
+                }
+            }
+            __syncthreads();
+        }
+        if (lane < cc) values[(size_t)v * C + c0 + lane] = acc;
     }
-    values[gid] = acc;
 }
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
-    const long long total = (long long)L.m_bound * C;
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const dim3 grid((unsigned)L.m_bound), block(64);
     if (mode == 0) splat_gather_kernel<0><<<grid, block, 0, s>>>(L, src, C, values);
     else if (mode == 1) splat_gather_kernel<1><<<grid, block, 0, s>>>(L, src, C, values);
     else splat_gather_kernel<2><<<grid, block, 0, s>>>(L, src, C, values);

@@ -165,10 +165,13 @@ static rvseg_status lattice_counters(rvseg_ctx* ctx, CrfState* cs, const Lattice
 }
 
 // DenseKernel::filter + PottsCompatibility::apply folded into tmp (pairwise.cpp:63-80,173-178)
-static void filter_into(const LatticeBufs& b, CrfState* cs, const ValueView& Q, int C, float w, float* tmp, hipStream_t s) {
+static void filter_into(rvseg_ctx* ctx, const LatticeBufs& b, CrfState* cs, const ValueView& Q, int C, float w, float* tmp, hipStream_t s) {
     const bool seq = C <= 2;  // Permutohedral::compute dispatch, permutohedral.cpp:600-603
+    timer_mark(ctx, "splat", s);
     launch_splat(b.dev, Q, C, 1, cs->val_a.as<float>(), s);
+    timer_mark(ctx, "blur", s);
     float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+    timer_mark(ctx, "slice", s);
     launch_slice(b.dev, C, seq, 2, blurred, -w, tmp, b.n_points, s);
 }
 
@@ -182,11 +185,14 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
     for (int k = 0; k < n_kernels; k++) mb = std::max<long long>(mb, cs->lat[k].dev.m_bound);
     if ((st = values_reserve(ctx, cs, mb, C)) != RVSEG_OK) return st;
     float* tmp = cs->tmp.as<float>();
+    timer_mark(ctx, "softmax", s);
     launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
     launch_softmax(tmp, C, N, Q, n_points, s);
     for (int it = 0; it < iterations; it++) {
+        timer_mark(ctx, "softmax", s);
         launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
-        for (int k = 0; k < n_kernels; k++) filter_into(cs->lat[k], cs, Q, C, ws[k], tmp, s);
+        for (int k = 0; k < n_kernels; k++) filter_into(ctx, cs->lat[k], cs, Q, C, ws[k], tmp, s);
+        timer_mark(ctx, "softmax", s);
         launch_softmax(tmp, C, N, Q, n_points, s);
     }
     RV_HIP(ctx, hipGetLastError());
@@ -231,7 +237,6 @@ rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rg
         if ((st = dev_reserve(ctx, cs->q, frame_stride * 4 * n)) != RVSEG_OK) return st;
         marg = cs->q.as<float>();
     }
-    timer_mark(ctx, "mean_field", s);
     int prefix = 0;
     const float w = p.dcrf_kernel_weight;
     for (int l = 0; l < f.n_layers; l++) {
@@ -314,7 +319,6 @@ rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t N, int32_t C, int32_t
     RV_HIP(ctx, hipMemcpyAsync(cs->unary.p, unary_energy, tot * 4, hipMemcpyHostToDevice, s));
     ValueView U{cs->unary.as<float>(), tot, 0}, Q{cs->q.as<float>(), tot, 0};
     timer_reset(ctx);
-    timer_mark(ctx, "mean_field", s);
     if ((st = mean_field(ctx, cs, n_kernels, ws, U, true, C, N, N, iterations, Q, s)) != RVSEG_OK) return st;
     timer_mark(ctx, "end", s);
     RV_HIP(ctx, hipMemcpyAsync(Q_out, cs->q.p, tot * 4, hipMemcpyDeviceToHost, s));
