@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="key frames per step and GPU")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
     return ap.parse_args()
 
 
@@ -141,7 +142,8 @@ def main():
     stages = ctx.last_timing()
     # single-frame latency (configs[1]) -- outside the timed region
     lat = None
-    if rank == 0:
+    stages_single = {}
+    if rank == 0 and not args.no_latency:
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         reps = 5
@@ -150,6 +152,7 @@ def main():
                                       d_labels.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize(dev)
         lat = (time.perf_counter() - t1) / reps * 1e3
+        stages_single = ctx.last_timing()
         # overflow / async error check of the last call
         ctx.segment_frames_device(1, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
                                   d_labels.data_ptr(), stream.cuda_stream)
@@ -184,6 +187,7 @@ def main():
             "pipeline_hbm_frac": round(PIPELINE_BYTES_PER_PX * value * 1e6 / n_gpus / (HBM_PEAK_GBS * 1e9), 5),
             "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
             "latency_ms_single_frame": round(lat, 3) if lat else None,
+            "stage_ms_single_frame": {k: round(v, 3) for k, v in stages_single.items()},
         }
         if n_gpus == 1 and not args.no_cpu and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, blob, rgb_h, depth_h, calib)

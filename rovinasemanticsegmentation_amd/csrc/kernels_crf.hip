@@ -335,88 +335,110 @@ void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
 // LDS; then lane c adds the tile's products of class c in list order -- the only part that has to
 // be sequential.  The next tile's loads are issued before the sequential phase so that their
 // latency hides behind the dependent adds.
-constexpr int SPLAT_CC = 16;  // classes per pass (LDS: 16 x 65 floats per wave)
+constexpr int SPLAT_R = 4;    // register ring: entries are loaded 3 tiles ahead, Q rows gathered 2 ahead
 
-template <int MODE>  // 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
+// CC = classes handled by this pass (compile time, so the body is branch-free and the compiler
+// keeps counted vmcnt waits); classes [c0, c0 + n_store) are stored, n_store <= CC; lanes of the
+// padding classes re-read class c0 + n_store - 1 and drop the result.
+template <int MODE, int CC>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
 __global__ void __launch_bounds__(64)
-splat_gather_kernel(LatticeDev L, ValueView src, int C, float* __restrict__ values) {
-    __shared__ __attribute__((aligned(16))) float prod[SPLAT_CC][68];  // 16-B aligned rows, 4-bank skew
+splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
+    __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
     const int v = blockIdx.x;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
     if (v >= M) return;
     const int lane = threadIdx.x;
     const unsigned k0 = L.vstart[v], k1 = L.vend[v];
-    for (int c0 = 0; c0 < C; c0 += SPLAT_CC) {
-        const int cc = C - c0 < SPLAT_CC ? C - c0 : SPLAT_CC;
-        float acc = 0.0f;
-        float x[SPLAT_CC];
-        float w = 0.f, nrm = 1.f;
-        // prefetch tile 0
-        {
-            const unsigned k = k0 + lane;
-            if (k < k1) {
-                w = L.csr_w[k];
-                if (MODE != 2) {
-                    const unsigned p = L.csr_pix[k];
-                    if (MODE == 1) nrm = L.csr_nrm[k];
-                    const size_t row = src.index(p, c0, C, L.N);
-#pragma unroll
-                    for (int c = 0; c < SPLAT_CC; c++) if (c < cc) x[c] = src.base[row + c];
-                }
-            }
-        }
-        for (unsigned base = k0; base < k1; base += 64) {
-            const unsigned n_valid = k1 - base < 64u ? k1 - base : 64u;
-            if ((unsigned)lane < n_valid) {
-#pragma unroll
-                for (int c = 0; c < SPLAT_CC; c++) {
-                    if (c < cc) {
-                        float xin = MODE == 2 ? 1.0f : x[c];
-                        if (MODE == 1) xin = xin * nrm;
-                        prod[c][lane] = w * xin;
-                    }
-                }
-            }
-            __syncthreads();
-            // issue the next tile's loads; they complete while the adds below run
-            {
-                const unsigned k = base + 64 + lane;
-                if (k < k1) {
-                    w = L.csr_w[k];
-                    if (MODE != 2) {
-                        const unsigned p = L.csr_pix[k];
-                        if (MODE == 1) nrm = L.csr_nrm[k];
-                        const size_t row = src.index(p, c0, C, L.N);
-#pragma unroll
-                        for (int c = 0; c < SPLAT_CC; c++) if (c < cc) x[c] = src.base[row + c];
-                    }
-                }
-            }
-            if (lane < cc) {
-                const float* pr = prod[lane];
-                if (n_valid == 64u) {
-                    // all 16 quad reads are issued before the first add: one LDS round trip per
-                    // tile instead of one per element; the adds stay strictly in list order
-                    float4 q[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
-                } else {
-                    for (unsigned k = 0; k < n_valid; k++) acc += pr[k];
-                }
-            }
-            __syncthreads();
-        }
-        if (lane < cc) values[(size_t)v * C + c0 + lane] = acc;
+    const unsigned n_tiles = (k1 - k0 + 63u) / 64u;
+    if (n_tiles == 0) {  // vertex created by a padding lane only: no mass
+        if (lane < n_store) values[(size_t)v * C + c0 + lane] = 0.0f;
+        return;
     }
+    float acc = 0.0f;
+    float x[SPLAT_R][CC];
+    float w[SPLAT_R], nrm[SPLAT_R];
+    unsigned pix[SPLAT_R];
+#pragma unroll
+    for (int r = 0; r < SPLAT_R; r++) { w[r] = 0.f; nrm[r] = 1.f; pix[r] = 0u; }
+
+    // Loads are unconditional (indices clamped into the vertex's list) so that no divergent branch
+    // forces the compiler to drain the memory queue.
+    auto load_entries = [&](unsigned tile, int slot) {
+        unsigned k = k0 + tile * 64u + lane;
+        k = k < k1 ? k : k1 - 1u;
+        w[slot] = L.csr_w[k];
+        if (MODE != 2) pix[slot] = L.csr_pix[k];
+        if (MODE == 1) nrm[slot] = L.csr_nrm[k];
+    };
+    auto gather_rows = [&](int slot) {
+        if (MODE == 2) return;
+        const size_t row = src.index(pix[slot], c0, C, L.N);
+#pragma unroll
+        for (int c = 0; c < CC; c++) x[slot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+    };
+    // prologue: entries of tiles 0..2, rows of tiles 0..1
+    load_entries(0, 0); load_entries(1, 1); load_entries(2, 2);
+    gather_rows(0); gather_rows(1);
+
+    for (unsigned t0 = 0; t0 < n_tiles; t0 += SPLAT_R) {
+#pragma unroll
+        for (int s = 0; s < SPLAT_R; s++) {
+            const unsigned t = t0 + s;
+            if (t < n_tiles) {   // uniform across the wave
+                const unsigned base = k0 + t * 64u;
+                const unsigned n_valid = k1 - base < 64u ? k1 - base : 64u;
+#pragma unroll
+                for (int c = 0; c < CC; c++) {
+                    float xin = MODE == 2 ? 1.0f : x[s][c];
+                    if (MODE == 1) xin = xin * nrm[s];
+                    prod[c][lane] = w[s] * xin;   // lanes >= n_valid hold a clamped duplicate, never added
+                }
+                __syncthreads();
+                // keep the memory pipeline full while the dependent adds below run
+                load_entries(t + 3, (s + 3) % SPLAT_R);
+                gather_rows((s + 2) % SPLAT_R);
+                if (lane < CC) {
+                    const float* pr = prod[lane];
+                    if (n_valid == 64u) {
+                        // all 16 quad reads are issued before the first add: one LDS round trip per
+                        // tile; the adds stay strictly in list order
+                        float4 q[16];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+                    } else {
+                        for (unsigned k = 0; k < n_valid; k++) acc += pr[k];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (lane < n_store) values[(size_t)v * C + c0 + lane] = acc;
+}
+
+template <int MODE>
+static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
+    const dim3 grid((unsigned)L.m_bound), block(64);
+    if (n == 1) splat_gather_kernel<MODE, 1><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else if (n == 2) splat_gather_kernel<MODE, 2><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else if (n <= 4) splat_gather_kernel<MODE, 4><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else if (n <= 8) splat_gather_kernel<MODE, 8><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else if (n == 9) splat_gather_kernel<MODE, 9><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else splat_gather_kernel<MODE, 16><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
 }
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
-    const dim3 grid((unsigned)L.m_bound), block(64);
-    if (mode == 0) splat_gather_kernel<0><<<grid, block, 0, s>>>(L, src, C, values);
-    else if (mode == 1) splat_gather_kernel<1><<<grid, block, 0, s>>>(L, src, C, values);
-    else splat_gather_kernel<2><<<grid, block, 0, s>>>(L, src, C, values);
+    if (mode == 2) {
+        splat_gather_kernel<2, 1><<<dim3((unsigned)L.m_bound), dim3(64), 0, s>>>(L, src, 1, 0, 1, values);
+        return;
+    }
+    for (int c0 = 0; c0 < C; c0 += 16) {
+        const int n = C - c0 < 16 ? C - c0 : 16;
+        if (mode == 0) splat_pass<0>(L, src, C, c0, n, values, s);
+        else splat_pass<1>(L, src, C, c0, n, values, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
