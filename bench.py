@@ -39,6 +39,7 @@ STAGE_BYTES_PER_PX = {
     "splat": 4.0 * C_CLASSES + 8.0 * (D_FEAT + 1),
     "blur": 0.0,
     "slice": 8.0 * (D_FEAT + 1) + 4.0 * C_CLASSES + 4,
+    "mf_update": 8.0 * (D_FEAT + 1) + 4.0 * C_CLASSES + 4 + 4.0 * C_CLASSES,  # slice reads + Q write
     "labels": 4.0 * C_CLASSES + 1,
 }
 PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.md 8d
@@ -162,7 +163,7 @@ def main():
         px_per_step = n * N
         value = n_gpus * px_per_step * args.steps / dt / 1e6
         # dominant stage and its roofline position
-        launches = {"softmax": CRF_ITERS + 1, "splat": CRF_ITERS, "blur": CRF_ITERS, "slice": CRF_ITERS}
+        launches = {"softmax": 1, "splat": CRF_ITERS, "blur": CRF_ITERS, "slice": CRF_ITERS, "mf_update": CRF_ITERS}
         dom = max(stages, key=stages.get) if stages else None
         roof = None
         if dom:

@@ -60,11 +60,15 @@ __device__ __forceinline__ bool key_equal_at(const unsigned long long* tkeys, un
     return a == mine[0] && b == mine[1];
 }
 
-// find-or-create; returns the slot.  On overflow sets counters[1] and returns 0.
-__device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* tkeys, unsigned mask, int* counters,
-                                                const Key8& key) {
-    unsigned h = hash_key(key) & mask;
+// The table is partitioned by frame: frame f owns slots [f*cap_f, (f+1)*cap_f).  Slot order is
+// therefore frame-major, and the scan-based compaction below numbers a frame's vertices
+// contiguously (the fused update kernel stages one frame's vertex values in LDS).
+// find-or-create; returns the global slot.  On overflow sets counters[1] and returns the region base.
+__device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* tkeys, unsigned base, unsigned mask,
+                                                int* counters, const Key8& key) {
+    unsigned hl = hash_key(key) & mask;
     for (unsigned probes = 0; probes <= mask; ) {
+        const unsigned h = base + hl;
         int st = __hip_atomic_load(state + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (st == ST_EMPTY) {
             int expected = ST_EMPTY;
@@ -74,29 +78,29 @@ __device__ __forceinline__ unsigned hash_insert(int* state, unsigned long long* 
                 __hip_atomic_store(tkeys + 2 * (size_t)h, mine[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(tkeys + 2 * (size_t)h + 1, mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(state + h, ST_FILLED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                const int filled = atomicAdd(counters + 2, 1) + 1;
-                if ((unsigned)filled > (mask >> 1) + 1) counters[1] = 1;  // load factor above 1/2
                 return h;
             }
             continue;  // lost the race: look at the same slot again
         }
         if (st == ST_LOCKED) continue;  // the owner publishes within its own loop iteration
         if (key_equal_at(tkeys, h, key)) return h;
-        h = (h + 1) & mask;
+        hl = (hl + 1) & mask;
         probes++;
     }
     counters[1] = 1;
-    return 0;
+    return base;
 }
 
 // read-only lookup (table complete, written by earlier kernels)
-__device__ __forceinline__ int hash_lookup(const int* state, const unsigned long long* tkeys, unsigned mask, const Key8& key) {
-    unsigned h = hash_key(key) & mask;
+__device__ __forceinline__ int hash_lookup(const int* state, const unsigned long long* tkeys, unsigned base, unsigned mask,
+                                           const Key8& key) {
+    unsigned hl = hash_key(key) & mask;
     const unsigned long long* mine = key.q;
     for (unsigned probes = 0; probes <= mask; probes++) {
+        const unsigned h = base + hl;
         if (state[h] == ST_EMPTY) return -1;
         if (tkeys[2 * (size_t)h] == mine[0] && tkeys[2 * (size_t)h + 1] == mine[1]) return (int)h;
-        h = (h + 1) & mask;
+        hl = (hl + 1) & mask;
     }
     return -1;
 }
@@ -206,7 +210,24 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
             key.k[k] = (short)(rem0[k] + (float)canon);
         }
         key.k[7] = (short)frame;
-        const unsigned slot = hash_insert(L.state, L.tkeys, L.cap_mask, L.counters, key);
+        // Neighbouring points mostly share their vertices: lanes holding the same key elect one
+        // leader that does the global find-or-create, the others take its answer by shuffle.
+        unsigned slot = 0;
+        bool pending = true;
+        const int lane = threadIdx.x & 63;
+        for (;;) {
+            const unsigned long long todo = __ballot(pending);
+            if (!todo) break;
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned l0 = __shfl(key.w[0], leader, 64), l1 = __shfl(key.w[1], leader, 64);
+            const unsigned l2 = __shfl(key.w[2], leader, 64), l3 = __shfl(key.w[3], leader, 64);
+            const bool same = pending && key.w[0] == l0 && key.w[1] == l1 && key.w[2] == l2 && key.w[3] == l3;
+            unsigned got = 0;
+            if (lane == leader)
+                got = hash_insert(L.state, L.tkeys, (unsigned)frame << L.cap_f_log2, L.cap_f_mask, L.counters, key);
+            got = __shfl(got, leader, 64);
+            if (same) { slot = got; pending = false; }
+        }
         if (real) {
             L.offsets[gp * (D + 1) + r] = (int)slot;
             L.bary[gp * (D + 1) + r] = bary[r];
@@ -230,19 +251,36 @@ void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStre
 }
 
 // ---------------------------------------------------------------------------------------------
-// compaction: filled slots -> dense vertex ids (arbitrary order), compact key array
+// compaction: an exclusive scan over the slot occupancy numbers the vertices in slot order, i.e.
+// deterministically and frame by frame
 // ---------------------------------------------------------------------------------------------
+struct SlotFilled {
+    __device__ __forceinline__ int operator()(int st) const { return st == ST_FILLED ? 1 : 0; }
+};
+
 __global__ void __launch_bounds__(256)
 lattice_compact_kernel(LatticeDev L) {
     const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot > L.cap_mask) return;
-    if (L.state[slot] == ST_FILLED) {
-        const int id = atomicAdd(L.counters + 0, 1);
-        L.slot_to_id[slot] = id;
-        if ((unsigned)id < (unsigned)L.m_bound) {
-            L.vkeys[2 * (size_t)id] = L.tkeys[2 * (size_t)slot];
-            L.vkeys[2 * (size_t)id + 1] = L.tkeys[2 * (size_t)slot + 1];
-        }
+    if (slot >= L.cap_total) return;
+    const bool filled = L.state[slot] == ST_FILLED;
+    const int id = L.slot_to_id[slot];
+    if (filled && (unsigned)id < (unsigned)L.m_bound) {
+        L.vkeys[2 * (size_t)id] = L.tkeys[2 * (size_t)slot];
+        L.vkeys[2 * (size_t)id + 1] = L.tkeys[2 * (size_t)slot + 1];
+    }
+    const unsigned cap_f = L.cap_f_mask + 1;
+    if ((slot & L.cap_f_mask) == 0) L.fstart[slot >> L.cap_f_log2] = id;   // first vertex id of the frame
+    if (slot == L.cap_total - 1) {
+        const int M = id + (filled ? 1 : 0);
+        L.counters[0] = M;
+        L.fstart[L.n_frames] = M;
+        if (M > L.m_bound) L.counters[1] = 1;
+    }
+    // load factor above 1/2 in a frame's region counts as overflow (checked at the region's last slot)
+    if ((slot & L.cap_f_mask) == L.cap_f_mask) {
+        const int first = L.slot_to_id[slot - L.cap_f_mask];
+        const int Mf = id + (filled ? 1 : 0) - first;
+        if ((unsigned)Mf > cap_f / 2) L.counters[1] = 1;
     }
 }
 
@@ -274,8 +312,9 @@ lattice_neighbours_kernel(LatticeDev L) {
     Key8 n1 = key, n2 = key;
     for (int k = 0; k < d; k++) { n1.k[k] = (short)(key.k[k] - 1); n2.k[k] = (short)(key.k[k] + 1); }
     if (j < d) { n1.k[j] = (short)(key.k[j] + d); n2.k[j] = (short)(key.k[j] - d); }
-    const int s1 = hash_lookup(L.state, L.tkeys, L.cap_mask, n1);
-    const int s2 = hash_lookup(L.state, L.tkeys, L.cap_mask, n2);
+    const unsigned fbase = (unsigned)(unsigned short)key.k[7] << L.cap_f_log2;
+    const int s1 = hash_lookup(L.state, L.tkeys, fbase, L.cap_f_mask, n1);
+    const int s2 = hash_lookup(L.state, L.tkeys, fbase, L.cap_f_mask, n2);
     L.nb1[(size_t)j * L.m_bound + id] = s1 < 0 ? -1 : L.slot_to_id[s1];
     L.nb2[(size_t)j * L.m_bound + id] = s2 < 0 ? -1 : L.slot_to_id[s2];
 }
@@ -295,7 +334,12 @@ lattice_csr_kernel(LatticeDev L, const unsigned* __restrict__ keys_sorted, const
 }
 
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
-    const unsigned cap = L.cap_mask + 1;
+    const unsigned cap = L.cap_total;
+    {
+        size_t temp = sb.scan_temp_bytes;
+        auto in = rocprim::make_transform_iterator(L.state, SlotFilled());
+        (void)rocprim::exclusive_scan(sb.scan_temp, temp, in, L.slot_to_id, 0, (size_t)cap, rocprim::plus<int>(), s);
+    }
     lattice_compact_kernel<<<dim3((cap + 255) / 256), dim3(256), 0, s>>>(L);
     lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
     const long long nb_threads = (long long)L.m_bound * (L.d + 1);
@@ -305,6 +349,14 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
                                     (unsigned)sb.key_bits, s);
     lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+}
+
+size_t scan_temp_bytes(unsigned cap) {
+    size_t temp = 0;
+    int* nul = nullptr;
+    auto in = rocprim::make_transform_iterator(nul, SlotFilled());
+    (void)rocprim::exclusive_scan(nullptr, temp, in, nul, 0, (size_t)cap, rocprim::plus<int>(), (hipStream_t)0);
+    return temp;
 }
 
 size_t sort_temp_bytes(long long n_entries, int key_bits) {
@@ -572,6 +624,111 @@ softmax_kernel(const float* __restrict__ tmp, int C, int N, ValueView q, long lo
 
 void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {
     softmax_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(tmp, C, N, q, n_points);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused mean-field update for ONE Potts kernel (the Segmenter's case, segmenter.cpp:641-644):
+//   slice (permutohedral.cpp:574-584) -> * norm (pairwise.cpp:79) -> * -w (labelcompatibility.cpp:47)
+//   -> tmp1 = -U - tmp2 (densecrf.cpp:123-126) -> expAndNormalize (densecrf.cpp:98-106)
+// One thread per point, all C classes in registers.  Vertex ids are frame-contiguous, so a block
+// (256 points of one frame) stages that frame's blurred vertex values in LDS when they fit and
+// slices from there; otherwise it gathers from HBM/L2.  Same operation order as the unfused
+// kernels, so the result is bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int MF_LDS_BYTES = 48 * 1024;
+
+template <bool SEQ, int C>
+__global__ void __launch_bounds__(256)
+mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float neg_w, ValueView unary, int negate,
+                 ValueView Q) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    constexpr int CP = (C + 3) / 4 * 4;
+    const int bpf = (L.N + 255) / 256;
+    const int frame = blockIdx.x / bpf;
+    const int i = (blockIdx.x - frame * bpf) * 256 + threadIdx.x;
+    const int f0 = L.fstart[frame], f1 = L.fstart[frame + 1];
+    const int Mf = f1 - f0;
+    const bool use_lds = (size_t)Mf * CP * sizeof(float) <= (size_t)MF_LDS_BYTES;
+    if (use_lds) {
+        for (int idx = threadIdx.x; idx < Mf * C; idx += 256) {
+            const int r = idx / C, c = idx - r * C;
+            tab[r * CP + c] = values[(size_t)(f0 + r) * C + c];
+        }
+        __syncthreads();
+    }
+    if (i >= L.N) return;
+    const size_t p = (size_t)frame * L.N + i;
+    const int dp1 = L.d + 1;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c] = 0.0f;
+    for (int j = 0; j < dp1; j++) {
+        const int o = L.offsets[p * dp1 + j];
+        const float bw = L.bary[p * dp1 + j];
+        float val[C];
+        if (use_lds) {
+            const float* row = tab + (o - f0) * CP;
+#pragma unroll
+            for (int c = 0; c < C; c++) val[c] = row[c];
+        } else {
+            const float* row = values + (size_t)o * C;
+#pragma unroll
+            for (int c = 0; c < C; c++) val[c] = row[c];
+        }
+        if (SEQ) {
+#pragma unroll
+            for (int c = 0; c < C; c++) { const float t = bw * val[c]; const float u = t * alpha; acc[c] += u; }
+        } else {
+            const float w = bw * alpha;
+#pragma unroll
+            for (int c = 0; c < C; c++) { const float prod = w * val[c]; acc[c] += prod; }
+        }
+    }
+    const float nrm = L.norm[p];
+    const size_t urow = unary.index((unsigned)p, 0, C, L.N);
+    float b[C];
+    float mx;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float t = acc[c] * nrm;
+        const float m = neg_w * t;
+        const float u = unary.base[urow + c];
+        b[c] = (negate ? -u : u) - m;
+    }
+    mx = b[0];
+#pragma unroll
+    for (int c = 1; c < C; c++) if (b[c] > mx) mx = b[c];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
+    const size_t qrow = Q.index((unsigned)p, 0, C, L.N);
+#pragma unroll
+    for (int c = 0; c < C; c++) Q.base[qrow + c] = b[c] / sum;
+}
+
+// returns false when C has no fused instantiation (the caller then runs the unfused kernels)
+bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
+                      const ValueView& Q, hipStream_t s) {
+    const float alpha = 1.0f / (1 + powf(2, (float)-L.d));
+    const int bpf = (L.N + 255) / 256;
+    const dim3 grid((unsigned)(bpf * L.n_frames)), block(256);
+#define RV_MF(SEQ, CC) mf_update_kernel<SEQ, CC><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q); return true
+    switch (C) {
+        case 2: RV_MF(true, 2);
+        case 3: RV_MF(false, 3);
+        case 4: RV_MF(false, 4);
+        case 5: RV_MF(false, 5);
+        case 6: RV_MF(false, 6);
+        case 7: RV_MF(false, 7);
+        case 8: RV_MF(false, 8);
+        case 9: RV_MF(false, 9);
+        case 10: RV_MF(false, 10);
+        case 12: RV_MF(false, 12);
+        case 16: RV_MF(false, 16);
+        case 21: RV_MF(false, 21);
+        default: return false;
+    }
+#undef RV_MF
 }
 
 __global__ void __launch_bounds__(256)

@@ -14,13 +14,16 @@ struct LatticeDev {
     int N;          // points per frame
     int Npad;       // N rounded up to a multiple of 4 (SSE block padding, permutohedral.cpp:196)
     int n_frames;
-    unsigned cap_mask;  // hash capacity (all frames) - 1
+    unsigned cap_f_mask;   // per-frame hash capacity - 1 (power of two)
+    unsigned cap_f_log2;
+    unsigned cap_total;    // n_frames * per-frame capacity
     int m_bound;        // capacity of the per-vertex arrays
     float scale[8];     // diagonal of E, permutohedral.cpp:177-182
     int* state;                  // per slot: EMPTY / LOCKED / FILLED
     unsigned long long* tkeys;   // per slot: 8 x int16 key (d coordinates .. frame)
     int* slot_to_id;
-    int* counters;               // [0] vertices M, [1] overflow flag, [2] filled slots
+    int* counters;               // [0] vertices M, [1] overflow flag
+    int* fstart;                 // n_frames + 1: first vertex id of each frame (ids are frame-contiguous)
     unsigned long long* vkeys;   // per vertex id: key
     int* offsets;                // P x (d+1): slot, later vertex id
     float* bary;                 // P x (d+1)
@@ -61,12 +64,15 @@ struct SortBuffers {
     void* temp;
     size_t temp_bytes;
     int key_bits;
+    void* scan_temp;
+    size_t scan_temp_bytes;
 };
 
 void launch_fill_int(int* p, int v, long long n, hipStream_t s);
 void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s);
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s);
 size_t sort_temp_bytes(long long n_entries, int key_bits);
+size_t scan_temp_bytes(unsigned cap);
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s);
@@ -74,6 +80,9 @@ float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a,
 // out_mode 0: plain, 1: normaliser, 2: inference update (tmp -= (-w) * (sliced * norm))
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
                   long long n_points, hipStream_t s);
+// fused slice + Potts + softmax for a single pairwise kernel; false if C is not instantiated
+bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
+                      const ValueView& Q, hipStream_t s);
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);
 void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
 

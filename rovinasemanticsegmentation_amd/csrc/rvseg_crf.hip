@@ -11,7 +11,7 @@ namespace rvseg {
 
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pix, csr_w, csr_nrm, vstart, vend, norm;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -38,7 +38,7 @@ static CrfState* crf_state(Pipeline* im) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pix, &b.csr_w, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -73,9 +73,9 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     if (d < 1 || d > 7) { ctx->err = "feature dimension must be in [1,7]"; return RVSEG_ERR_INVALID_ARG; }
     if (n_frames > 32767) { ctx->err = "too many frames per chunk"; return RVSEG_ERR_INVALID_ARG; }
     const int Npad = (N + 3) / 4 * 4;
-    const int cap_log2 = capacity_log2_per_frame(ctx, Npad, d, safe) + ceil_log2((unsigned long long)n_frames);
-    if (cap_log2 > 31) { ctx->err = "lattice hash capacity too large"; return RVSEG_ERR_CAPACITY; }
-    const unsigned long long cap = 1ull << cap_log2;
+    const int cap_f_log2 = capacity_log2_per_frame(ctx, Npad, d, safe);
+    const unsigned long long cap = (unsigned long long)n_frames << cap_f_log2;
+    if (cap >= (1ull << 31)) { ctx->err = "lattice hash capacity too large (lower max_batch or lattice_capacity_log2)"; return RVSEG_ERR_CAPACITY; }
     const unsigned long long worst = (unsigned long long)Npad * n_frames * (d + 1);
     const unsigned long long m_bound = std::min<unsigned long long>(cap / 2 + 2, worst);
     const long long P = (long long)N * n_frames;
@@ -87,6 +87,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.tkeys, cap * 16);
     RV_RES(b.slot_to_id, cap * 4);
     RV_RES(b.counters, 16);
+    RV_RES(b.fstart, ((size_t)n_frames + 1) * 4);
     RV_RES(b.vkeys, m_bound * 16);
     RV_RES(b.offsets, E * 4);
     RV_RES(b.bary, E * 4);
@@ -105,16 +106,20 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     const int key_bits = std::max(1, ceil_log2(m_bound));
     const size_t temp = sort_temp_bytes(E, key_bits);
     RV_RES(b.sort_temp, temp);
+    const size_t stemp = scan_temp_bytes((unsigned)cap);
+    RV_RES(b.scan_temp, stemp);
 #undef RV_RES
     LatticeDev& L = b.dev;
     L.d = d; L.N = N; L.Npad = Npad; L.n_frames = n_frames;
-    L.cap_mask = (unsigned)(cap - 1);
+    L.cap_f_log2 = (unsigned)cap_f_log2;
+    L.cap_f_mask = (1u << cap_f_log2) - 1u;
+    L.cap_total = (unsigned)cap;
     L.m_bound = (int)m_bound;
     // diagonal of E (permutohedral.cpp:177-182): float inv_std_dev; scale = 1/sqrt((i+2)(i+1)) * inv_std_dev
     const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (d + 1));
     for (int i = 0; i < 8; i++) L.scale[i] = i < d ? (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * inv_std_dev) : 0.f;
     L.state = b.state.as<int>(); L.tkeys = b.tkeys.as<unsigned long long>(); L.slot_to_id = b.slot_to_id.as<int>();
-    L.counters = b.counters.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
+    L.counters = b.counters.as<int>(); L.fstart = b.fstart.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
     L.offsets = b.offsets.as<int>(); L.bary = b.bary.as<float>();
     L.nb1 = b.nb1.as<int>(); L.nb2 = b.nb2.as<int>();
     L.csr_pix = b.csr_pix.as<unsigned>(); L.csr_w = b.csr_w.as<float>(); L.csr_nrm = b.csr_nrm.as<float>();
@@ -122,6 +127,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.keys_in = b.keys_in.as<unsigned>(); b.sb.keys_out = b.keys_out.as<unsigned>();
     b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
+    b.sb.scan_temp = b.scan_temp.p; b.sb.scan_temp_bytes = stemp;
     b.n_entries = E; b.n_points = P;
     b.built = false;
     return RVSEG_OK;
@@ -137,7 +143,7 @@ static rvseg_status values_reserve(rvseg_ctx* ctx, CrfState* cs, long long m_bou
 // Permutohedral::init + the normaliser of DenseKernel::initLattice (pairwise.cpp:40-56)
 static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, const FeatureSource& fs, hipStream_t s) {
     const LatticeDev& L = b.dev;
-    RV_HIP(ctx, hipMemsetAsync(L.state, 0xFF, ((size_t)L.cap_mask + 1) * 4, s));
+    RV_HIP(ctx, hipMemsetAsync(L.state, 0xFF, (size_t)L.cap_total * 4, s));
     RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
     RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
     RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
@@ -189,6 +195,24 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
     launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
     launch_softmax(tmp, C, N, Q, n_points, s);
     for (int it = 0; it < iterations; it++) {
+        if (n_kernels == 1) {
+            // single Potts kernel: splat, blur, then one fused slice + update + softmax pass
+            const LatticeBufs& b = cs->lat[0];
+            const bool seq = C <= 2;
+            timer_mark(ctx, "splat", s);
+            launch_splat(b.dev, Q, C, 1, cs->val_a.as<float>(), s);
+            timer_mark(ctx, "blur", s);
+            float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+            timer_mark(ctx, "mf_update", s);
+            if (launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, s)) continue;
+            timer_mark(ctx, "softmax", s);
+            launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
+            timer_mark(ctx, "slice", s);
+            launch_slice(b.dev, C, seq, 2, blurred, -ws[0], tmp, n_points, s);
+            timer_mark(ctx, "softmax", s);
+            launch_softmax(tmp, C, N, Q, n_points, s);
+            continue;
+        }
         timer_mark(ctx, "softmax", s);
         launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
         for (int k = 0; k < n_kernels; k++) filter_into(ctx, cs->lat[k], cs, Q, C, ws[k], tmp, s);
