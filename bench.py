@@ -105,7 +105,7 @@ def main():
     d_depth = torch.from_numpy(depth_h.view(np.int16)).to(dev)
     d_marg = torch.empty((n, C_CLASSES * N), dtype=torch.float32, device=dev)
     d_labels = torch.empty((n, N), dtype=torch.int8, device=dev)
-    gathered = [torch.empty_like(d_labels) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from rovinasemanticsegmentation_amd.distributed import gather_labels
 
     ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=CRF_ITERS, label_mode=rv.capi.LABEL_CRF,
                      unknown_label=[8], max_batch=n, device=dev.index or 0,
@@ -119,7 +119,7 @@ def main():
         ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
                                   d_labels.data_ptr(), stream.cuda_stream)
         if world > 1:  # local-map label fusion: one gather to the fusion rank over xGMI
-            dist.gather(d_labels, gathered, dst=0)
+            gather_labels(d_labels, n * world, dst=0)
 
     def barrier():
         if world > 1:

@@ -731,6 +731,38 @@ bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg
 #undef RV_MF
 }
 
+// Q0 = expAndNormalize(-U) straight from the unary (densecrf.cpp:120), one thread per point
+template <int C>
+__global__ void __launch_bounds__(256)
+softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long n_points) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_points) return;
+    const size_t urow = unary.index((unsigned)p, 0, C, N);
+    float b[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) { const float u = unary.base[urow + c]; b[c] = negate ? -u : u; }
+    float mx = b[0];
+#pragma unroll
+    for (int c = 1; c < C; c++) if (b[c] > mx) mx = b[c];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
+    const size_t qrow = q.index((unsigned)p, 0, C, N);
+#pragma unroll
+    for (int c = 0; c < C; c++) q.base[qrow + c] = b[c] / sum;
+}
+
+bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {
+    const dim3 grid((unsigned)((n_points + 255) / 256)), block(256);
+#define RV_SU(CC) softmax_unary_kernel<CC><<<grid, block, 0, s>>>(unary, negate ? 1 : 0, N, q, n_points); return true
+    switch (C) {
+        case 2: RV_SU(2); case 3: RV_SU(3); case 4: RV_SU(4); case 5: RV_SU(5); case 6: RV_SU(6); case 7: RV_SU(7);
+        case 8: RV_SU(8); case 9: RV_SU(9); case 10: RV_SU(10); case 12: RV_SU(12); case 16: RV_SU(16); case 21: RV_SU(21);
+        default: return false;
+    }
+#undef RV_SU
+}
+
 __global__ void __launch_bounds__(256)
 fill_int_kernel(int* p, int v, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -381,6 +381,47 @@ labels_kernel(const float* __restrict__ values, size_t n_points, int C, int mode
     labels[i] = (int8_t)best;
 }
 
+// labels of every frame and layer of a chunk: values in the posterior layout (frame stride
+// sumC*N, layer blocks of N*C_l), labels as n x L x N
+__global__ void __launch_bounds__(256)
+labels_frames_kernel(const float* __restrict__ values, int n_frames, int N, int C, size_t frame_stride, size_t layer_off,
+                     int n_layers, int layer, int mode, int unknown, int8_t* __restrict__ labels) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n_frames * N) return;
+    const size_t frame = gid / (size_t)N, i = gid - frame * (size_t)N;
+    const float* v = values + frame * frame_stride + layer_off + i * C;
+    int best;
+    float mx;
+    if (mode == RVSEG_LABEL_EVAL) {
+        best = -1; mx = -1000.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == RVSEG_LABEL_CRF) {
+        best = unknown; mx = (float)(2.0 / (double)C);
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == RVSEG_LABEL_NOCRF) {
+        best = unknown; mx = -1000.f;
+        float sum = 0.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; sum += x; if (x > mx) { mx = x; best = c; } }
+        if (!(sum != 0.0f)) best = unknown;
+    } else {
+        best = 0; mx = v[0];
+        for (int c = 1; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    }
+    labels[(frame * n_layers + layer) * (size_t)N + i] = (int8_t)best;
+}
+
+void launch_labels_frames(const float* d_values, int n_frames, int N, const DeviceForest& f, int mode, const int* unknown,
+                          int8_t* d_labels, hipStream_t s) {
+    const size_t total = (size_t)n_frames * N;
+    int prefix = 0;
+    for (int l = 0; l < f.n_layers; l++) {
+        labels_frames_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            d_values, n_frames, N, f.class_counts[l], (size_t)N * f.sum_classes, (size_t)N * prefix, f.n_layers, l, mode,
+            unknown[l], d_labels);
+        prefix += f.class_counts[l];
+    }
+}
+
 void launch_labels(const float* d_values, size_t n_points, int C, int mode, int unknown, int8_t* d_labels, hipStream_t s) {
     if (n_points == 0) return;
     labels_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(d_values, n_points, C, mode, unknown, d_labels);

@@ -84,6 +84,7 @@ void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const floa
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
                       const ValueView& Q, hipStream_t s);
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);
+bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
 void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
 
 }  // namespace rvseg

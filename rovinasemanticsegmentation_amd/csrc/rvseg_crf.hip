@@ -192,8 +192,10 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
     if ((st = values_reserve(ctx, cs, mb, C)) != RVSEG_OK) return st;
     float* tmp = cs->tmp.as<float>();
     timer_mark(ctx, "softmax", s);
-    launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
-    launch_softmax(tmp, C, N, Q, n_points, s);
+    if (!launch_softmax_unary(unary, unary_is_energy, C, N, Q, n_points, s)) {
+        launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
+        launch_softmax(tmp, C, N, Q, n_points, s);
+    }
     for (int it = 0; it < iterations; it++) {
         if (n_kernels == 1) {
             // single Potts kernel: splat, blur, then one fused slice + update + softmax pass
@@ -273,16 +275,7 @@ rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rg
     }
     if (d_labels) {
         timer_mark(ctx, "labels", s);
-        size_t loff = 0;
-        for (int i = 0; i < n; i++) {
-            prefix = 0;
-            for (int l = 0; l < f.n_layers; l++) {
-                launch_labels(marg + (size_t)i * frame_stride + (size_t)N * prefix, (size_t)N, f.class_counts[l], p.label_mode,
-                              p.unknown_label[l], d_labels + loff, s);
-                loff += (size_t)N;
-                prefix += f.class_counts[l];
-            }
-        }
+        launch_labels_frames(marg, n, N, f, p.label_mode, p.unknown_label, d_labels, s);
     }
     return RVSEG_OK;
 }

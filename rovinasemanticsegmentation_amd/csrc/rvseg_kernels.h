@@ -57,6 +57,8 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
 void launch_upsample_pack(const FrameGeom& g, const DeviceForest& f, const UpsampleTables& t,
                           const float* d_low, float* d_post, int n, hipStream_t s);
 // label rules (rvseg_label_mode) over N points x C classes, class-contiguous
+void launch_labels_frames(const float* d_values, int n_frames, int N, const DeviceForest& f, int mode, const int* unknown,
+                          int8_t* d_labels, hipStream_t s);
 void launch_labels(const float* d_values, size_t n_points, int C, int mode, int unknown, int8_t* d_labels,
                    hipStream_t s);
 

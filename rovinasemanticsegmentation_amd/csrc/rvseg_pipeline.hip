@@ -191,17 +191,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
         if (st != RVSEG_OK) return st;
     } else if (d_labels) {
         timer_mark(ctx, "labels", s);
-        size_t loff = 0;
-        int prefix = 0;
-        for (int i = 0; i < n; i++) {
-            prefix = 0;
-            for (int l = 0; l < f.n_layers; l++) {
-                launch_labels(post + (size_t)i * npix * f.sum_classes + npix * prefix, npix, f.class_counts[l], p.label_mode,
-                              p.unknown_label[l], d_labels + loff, s);
-                loff += npix;
-                prefix += f.class_counts[l];
-            }
-        }
+        launch_labels_frames(post, n, (int)npix, f, p.label_mode, p.unknown_label, d_labels, s);
     }
     timer_mark(ctx, "end", s);
     RV_HIP(ctx, hipGetLastError());

@@ -1,0 +1,67 @@
+"""Multi-process path on CPU: frame sharding + label gather with the gloo backend, world size 2
+(and 3 for uneven shards).  The same functions run over RCCL in bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rovinasemanticsegmentation_amd.distributed import gather_labels, shard_frames
+
+
+def test_shard_frames_partition():
+    for n in (0, 1, 7, 64, 256, 257):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_frames(n, r, world) for r in range(world)]
+            assert sum(c for _, c in blocks) == n
+            pos = 0
+            for s, c in blocks:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, count = shard_frames(n_frames, rank, world)
+        L, H, W = 2, 6, 8
+        # "labels" that encode (frame, layer, pixel) so that order and content are checkable
+        f = torch.arange(start, start + count).view(-1, 1, 1, 1)
+        l = torch.arange(L).view(1, -1, 1, 1)
+        p = torch.arange(H * W).view(1, 1, H, W)
+        local = ((f * 7 + l * 3 + p) % 120).to(torch.int8)
+        fused = gather_labels(local, n_frames, dst=0)
+        if rank == 0:
+            fa = torch.arange(n_frames).view(-1, 1, 1, 1)
+            want = ((fa * 7 + l * 3 + p) % 120).to(torch.int8)
+            q.put(bool(torch.equal(fused, want)) and tuple(fused.shape) == (n_frames, L, H, W))
+        else:
+            assert fused is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (2, 5), (3, 7)])
+def test_label_gather_gloo(world, n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
