@@ -333,6 +333,8 @@ lattice_csr_kernel(LatticeDev L, const unsigned* __restrict__ keys_sorted, const
     if (k == n_entries - 1 || keys_sorted[k + 1] != key) L.vend[key] = (unsigned)(k + 1);
 }
 
+void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s);
+
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
     const unsigned cap = L.cap_total;
     {
@@ -349,6 +351,24 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
                                     (unsigned)sb.key_bits, s);
     lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+    launch_vertex_order(L, sb, s);
+}
+
+// longest-list-first launch order of the vertices for the splat (LPT scheduling: the serial chain
+// of the heaviest vertices starts at t = 0, the short ones fill in behind)
+__global__ void __launch_bounds__(256)
+vertex_len_kernel(LatticeDev L, unsigned* __restrict__ len, unsigned* __restrict__ ids) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= L.m_bound) return;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    len[v] = v < M ? L.vend[v] - L.vstart[v] : 0u;
+    ids[v] = (unsigned)v;
+}
+
+void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
+    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in);
+    size_t temp = sb.temp_bytes;
+    (void)rocprim::radix_sort_pairs_desc(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
 }
 
 size_t scan_temp_bytes(unsigned cap) {
@@ -396,9 +416,9 @@ template <int MODE, int CC>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2
 __global__ void __launch_bounds__(64)
 splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
     __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
-    const int v = blockIdx.x;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
-    if (v >= M) return;
+    if ((int)blockIdx.x >= M) return;
+    const int v = (int)L.vorder[blockIdx.x];
     const int lane = threadIdx.x;
     const unsigned k0 = L.vstart[v], k1 = L.vend[v];
     const unsigned n_tiles = (k1 - k0 + 63u) / 64u;

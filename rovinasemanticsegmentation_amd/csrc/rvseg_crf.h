@@ -32,6 +32,7 @@ struct LatticeDev {
     float* csr_w;                // barycentric weight of the entry
     float* csr_nrm;              // norm[csr_pix] (available after the normaliser pass)
     unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
+    unsigned* vorder;            // vertex ids, longest list first (launch order of the splat)
     float* norm;                 // per point, pairwise.cpp:55-56
 };
 

@@ -11,7 +11,7 @@ namespace rvseg {
 
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pix, csr_w, csr_nrm, vstart, vend, norm;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -38,7 +38,7 @@ static CrfState* crf_state(Pipeline* im) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pix, &b.csr_w, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -98,13 +98,15 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.csr_nrm, E * 4);
     RV_RES(b.vstart, m_bound * 4);
     RV_RES(b.vend, m_bound * 4);
+    RV_RES(b.vorder, m_bound * 4);
     RV_RES(b.norm, P * 4);
-    RV_RES(b.keys_in, E * 4);
-    RV_RES(b.keys_out, E * 4);
-    RV_RES(b.vals_in, E * 4);
-    RV_RES(b.vals_out, E * 4);
+    const unsigned long long SE = std::max<unsigned long long>((unsigned long long)E, m_bound);  // also sorts the vertex order
+    RV_RES(b.keys_in, SE * 4);
+    RV_RES(b.keys_out, SE * 4);
+    RV_RES(b.vals_in, SE * 4);
+    RV_RES(b.vals_out, SE * 4);
     const int key_bits = std::max(1, ceil_log2(m_bound));
-    const size_t temp = sort_temp_bytes(E, key_bits);
+    const size_t temp = std::max(sort_temp_bytes(E, key_bits), sort_temp_bytes((long long)m_bound, 32));
     RV_RES(b.sort_temp, temp);
     const size_t stemp = scan_temp_bytes((unsigned)cap);
     RV_RES(b.scan_temp, stemp);
@@ -123,7 +125,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.offsets = b.offsets.as<int>(); L.bary = b.bary.as<float>();
     L.nb1 = b.nb1.as<int>(); L.nb2 = b.nb2.as<int>();
     L.csr_pix = b.csr_pix.as<unsigned>(); L.csr_w = b.csr_w.as<float>(); L.csr_nrm = b.csr_nrm.as<float>();
-    L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.norm = b.norm.as<float>();
+    L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.vorder = b.vorder.as<unsigned>(); L.norm = b.norm.as<float>();
     b.sb.keys_in = b.keys_in.as<unsigned>(); b.sb.keys_out = b.keys_out.as<unsigned>();
     b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
