@@ -108,15 +108,26 @@ __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long
 // ---------------------------------------------------------------------------------------------
 // Permutohedral::init per point (SSE branch semantics, fp32, no contraction)
 // ---------------------------------------------------------------------------------------------
+constexpr int LP_SET = 1024;       // block-local vertex set (256 points x (d+1) keys, few distinct)
+constexpr int LP_MAX_PROBE = 24;
+
 template <int D>
 __global__ void __launch_bounds__(256)
 lattice_points_kernel(LatticeDev L, FeatureSource fs) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // block-local vertex set: tag (EMPTY / LOCKED / FILLED), key, global slot
+    __shared__ int ltag[LP_SET];
+    __shared__ unsigned long long lkey[LP_SET][2];
+    __shared__ unsigned lslot[LP_SET];
+    for (int t = threadIdx.x; t < LP_SET; t += 256) ltag[t] = ST_EMPTY;
+    __syncthreads();
+
+    const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per_frame = L.Npad;
-    if (gid >= per_frame * L.n_frames) return;
+    const bool active = gid0 < per_frame * L.n_frames;   // all threads stay for the barriers
+    const long long gid = active ? gid0 : 0;
     const int frame = (int)(gid / per_frame);
     const int i = (int)(gid - (long long)frame * per_frame);
-    const bool real = i < L.N;
+    const bool real = active && i < L.N;
     const long long gp = (long long)frame * L.N + i;  // global point index (valid when real)
 
     float f[D];
@@ -197,7 +208,11 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
         }
     }
     bary[0] += 1.0f + bary[D + 1];
-    // vertices (:266-275)
+    // vertices (:266-275).  Neighbouring points share almost all their vertices, so the block first
+    // collects its distinct keys in an LDS set (phase 1), then one lane per distinct key does the
+    // global find-or-create -- all global round trips of a block overlap (phase 2) -- and finally
+    // every point reads the global slots of its d+1 vertices back from LDS (phase 3).
+    int lidx[D + 1];   // index into the LDS set, or -1 - (global slot) when the set was too full
 #pragma unroll
     for (int r = 0; r <= D; r++) {
         Key8 key;
@@ -210,26 +225,52 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
             key.k[k] = (short)(rem0[k] + (float)canon);
         }
         key.k[7] = (short)frame;
-        // Neighbouring points mostly share their vertices: lanes holding the same key elect one
-        // leader that does the global find-or-create, the others take its answer by shuffle.
-        unsigned slot = 0;
-        bool pending = true;
-        const int lane = threadIdx.x & 63;
-        for (;;) {
-            const unsigned long long todo = __ballot(pending);
-            if (!todo) break;
-            const int leader = __ffsll((long long)todo) - 1;
-            const unsigned l0 = __shfl(key.w[0], leader, 64), l1 = __shfl(key.w[1], leader, 64);
-            const unsigned l2 = __shfl(key.w[2], leader, 64), l3 = __shfl(key.w[3], leader, 64);
-            const bool same = pending && key.w[0] == l0 && key.w[1] == l1 && key.w[2] == l2 && key.w[3] == l3;
-            unsigned got = 0;
-            if (lane == leader)
-                got = hash_insert(L.state, L.tkeys, (unsigned)frame << L.cap_f_log2, L.cap_f_mask, L.counters, key);
-            got = __shfl(got, leader, 64);
-            if (same) { slot = got; pending = false; }
+        lidx[r] = 0;
+        if (active) {
+            unsigned h = (hash_key(key) >> 7) & (LP_SET - 1);
+            int found = -1;
+            for (int probes = 0; probes < LP_MAX_PROBE; ) {
+                const int t = __hip_atomic_load(&ltag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (t == ST_EMPTY) {
+                    int expected = ST_EMPTY;
+                    if (__hip_atomic_compare_exchange_strong(&ltag[h], &expected, ST_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        __hip_atomic_store(&lkey[h][0], key.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&lkey[h][1], key.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&ltag[h], ST_FILLED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        found = (int)h;
+                        break;
+                    }
+                    continue;
+                }
+                if (t == ST_LOCKED) continue;
+                const unsigned long long a = __hip_atomic_load(&lkey[h][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long b = __hip_atomic_load(&lkey[h][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (a == key.q[0] && b == key.q[1]) { found = (int)h; break; }
+                h = (h + 1) & (LP_SET - 1);
+                probes++;
+            }
+            if (found < 0)  // set too crowded around this key: go to the global table directly
+                found = -1 - (int)hash_insert(L.state, L.tkeys, (unsigned)frame << L.cap_f_log2, L.cap_f_mask, L.counters, key);
+            lidx[r] = found;
         }
-        if (real) {
-            L.offsets[gp * (D + 1) + r] = (int)slot;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < LP_SET; t += 256) {
+        if (ltag[t] == ST_FILLED) {
+            Key8 key;
+            key.q[0] = lkey[t][0];
+            key.q[1] = lkey[t][1];
+            const unsigned fr = (unsigned)(unsigned short)key.k[7];
+            lslot[t] = hash_insert(L.state, L.tkeys, fr << L.cap_f_log2, L.cap_f_mask, L.counters, key);
+        }
+    }
+    __syncthreads();
+    if (real) {
+#pragma unroll
+        for (int r = 0; r <= D; r++) {
+            const int li = lidx[r];
+            L.offsets[gp * (D + 1) + r] = li >= 0 ? (int)lslot[li] : -1 - li;
             L.bary[gp * (D + 1) + r] = bary[r];
         }
     }
@@ -354,21 +395,32 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     launch_vertex_order(L, sb, s);
 }
 
-// longest-list-first launch order of the vertices for the splat (LPT scheduling: the serial chain
-// of the heaviest vertices starts at t = 0, the short ones fill in behind)
+// Launch order of the vertices for the splat: grouped by (frame mod G) so that, with the
+// dispatcher dealing blocks round-robin over the 8 XCDs, every reader of a frame's Q rows runs on
+// the same XCD and shares its L2 (speed only, never correctness); inside a group longest list
+// first (LPT: the serial chains of the heaviest vertices start at t = 0).
 __global__ void __launch_bounds__(256)
-vertex_len_kernel(LatticeDev L, unsigned* __restrict__ len, unsigned* __restrict__ ids) {
+vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.m_bound) return;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
-    len[v] = v < M ? L.vend[v] - L.vstart[v] : 0u;
+    unsigned k = 0xFFFFFFFFu;  // unused ids sort to the end
+    if (v < M) {
+        const unsigned len = L.vend[v] - L.vstart[v];
+        const unsigned frame = (unsigned)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
+        const unsigned g = frame % (unsigned)L.n_groups;
+        k = (g << 28) | (0x0FFFFFFFu - (len < 0x0FFFFFFFu ? len : 0x0FFFFFFFu));
+        atomicAdd(L.gcount + g, 1u);
+    }
+    key[v] = k;
     ids[v] = (unsigned)v;
 }
 
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
+    (void)hipMemsetAsync(L.gcount, 0, 8 * sizeof(unsigned), s);
     vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in);
     size_t temp = sb.temp_bytes;
-    (void)rocprim::radix_sort_pairs_desc(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
+    (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
 }
 
 size_t scan_temp_bytes(unsigned cap) {
@@ -416,9 +468,12 @@ template <int MODE, int CC>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2
 __global__ void __launch_bounds__(64)
 splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
     __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
-    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
-    if ((int)blockIdx.x >= M) return;
-    const int v = (int)L.vorder[blockIdx.x];
+    // block b -> group b % G (= the XCD it lands on when G == 8), rank b / G inside the group
+    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j = blockIdx.x / (unsigned)L.n_groups;
+    if (j >= L.gcount[g]) return;
+    unsigned gstart = 0;
+    for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
+    const int v = (int)L.vorder[gstart + j];
     const int lane = threadIdx.x;
     const unsigned k0 = L.vstart[v], k1 = L.vend[v];
     const unsigned n_tiles = (k1 - k0 + 63u) / 64u;
@@ -492,7 +547,7 @@ splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, flo
 
 template <int MODE>
 static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
-    const dim3 grid((unsigned)L.m_bound), block(64);
+    const dim3 grid((unsigned)L.splat_grid), block(64);
     if (n == 1) splat_gather_kernel<MODE, 1><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
     else if (n == 2) splat_gather_kernel<MODE, 2><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
     else if (n <= 4) splat_gather_kernel<MODE, 4><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
@@ -503,7 +558,7 @@ static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0,
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
     if (mode == 2) {
-        splat_gather_kernel<2, 1><<<dim3((unsigned)L.m_bound), dim3(64), 0, s>>>(L, src, 1, 0, 1, values);
+        splat_gather_kernel<2, 1><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values);
         return;
     }
     for (int c0 = 0; c0 < C; c0 += 16) {

@@ -32,7 +32,10 @@ struct LatticeDev {
     float* csr_w;                // barycentric weight of the entry
     float* csr_nrm;              // norm[csr_pix] (available after the normaliser pass)
     unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
-    unsigned* vorder;            // vertex ids, longest list first (launch order of the splat)
+    unsigned* vorder;            // vertex ids in splat launch order (grouped by frame mod n_groups, longest first)
+    unsigned* gcount;            // vertices per group (8 counters)
+    int n_groups;                // 8 when the chunk has >= 8 frames, else 1
+    unsigned splat_grid;         // n_groups * (largest possible group)
     float* norm;                 // per point, pairwise.cpp:55-56
 };
 
