@@ -248,6 +248,89 @@ normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const u
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-tiled variant for stride <= 2: a block owns 8 x 16 sample points; the fixed-point gradients
+// of its pixel tile (+ 6-px apron) are formed once, cooperatively, and the window sums then run
+// entirely out of LDS.  Same integer sums, so the result is identical to the gather kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int NF_TY = 8, NF_TX = 16, NF_APRON = 6;
+
+__global__ void __launch_bounds__(NF_TY * NF_TX)
+normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const uint8_t* __restrict__ rect_all,
+                            float* __restrict__ nfeat_all, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) long long grad[];   // [th*tw][6], then flags
+    const int s = g.stride;
+    const int tw = NF_TX * s + 2 * NF_APRON, th = NF_TY * s + 2 * NF_APRON;
+    unsigned char* flags = reinterpret_cast<unsigned char*>(grad + (size_t)th * tw * 6);
+    const int W = g.W, H = g.H;
+    const int frame = blockIdx.x / (tiles_x * tiles_y);
+    const int tile = blockIdx.x - frame * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int px0 = tx * NF_TX * s - NF_APRON, py0 = ty * NF_TY * s - NF_APRON;   // pixel of LDS cell (0,0)
+    const float4* cloud = cloud_all + (size_t)frame * W * H;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < th * tw; idx += NF_TY * NF_TX) {
+        const int ly = idx / tw, lx = idx - ly * tw;
+        const int y = py0 + ly, x = px0 + lx;
+        long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
+        unsigned char fl = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            float dx0 = 0.f, dx1 = 0.f, dx2 = 0.f, dy0 = 0.f, dy1 = 0.f, dy2 = 0.f;
+            if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+                const float4 r = cloud[(size_t)y * W + x + 1], l = cloud[(size_t)y * W + x - 1];
+                const float4 dn = cloud[(size_t)(y + 1) * W + x], up = cloud[(size_t)(y - 1) * W + x];
+                dx0 = r.x - l.x; dx1 = r.y - l.y; dx2 = r.z - l.z;
+                dy0 = dn.x - up.x; dy1 = dn.y - up.y; dy2 = dn.z - up.z;
+            }
+            if (finite_f(dx0) && finite_f(dx1) && finite_f(dx2)) { fl |= 1; gx0 = to_fix32(dx0); gx1 = to_fix32(dx1); gx2 = to_fix32(dx2); }
+            if (finite_f(dy0) && finite_f(dy1) && finite_f(dy2)) { fl |= 2; gy0 = to_fix32(dy0); gy1 = to_fix32(dy1); gy2 = to_fix32(dy2); }
+        }
+        long long* d = grad + (size_t)idx * 6;
+        d[0] = gx0; d[1] = gx1; d[2] = gx2; d[3] = gy0; d[4] = gy1; d[5] = gy2;
+        flags[idx] = fl;
+    }
+    __syncthreads();
+    const int sy = tid / NF_TX, sx = tid - sy * NF_TX;
+    const int ly_s = ty * NF_TY + sy, lx_s = tx * NF_TX + sx;   // sample grid coordinates
+    if (ly_s >= g.lh || lx_s >= g.lw) return;
+    const int ri = ly_s * s, ci = lx_s * s;
+    float out = -2.0f;
+    const int border = 10;
+    if (ri >= border && ri < H - border && ci >= border && ci < W - border) {
+        const int rect = rect_all[(size_t)frame * W * H + (size_t)ri * W + ci];
+        const float zc = cloud[(size_t)ri * W + ci].z;
+        if (rect > 0 && finite_f(zc)) {
+            const int rect2 = rect >> 1;
+            const int wx = ci - rect2 - px0, wy = ri - rect2 - py0;   // window origin inside the tile
+            long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
+            int cnt_x = 0, cnt_y = 0;
+            for (int yy = wy; yy < wy + rect; yy++) {
+                for (int xx = wx; xx < wx + rect; xx++) {
+                    const int idx = yy * tw + xx;
+                    const long long* d = grad + (size_t)idx * 6;
+                    const unsigned char fl = flags[idx];
+                    cnt_x += fl & 1; cnt_y += (fl >> 1) & 1;
+                    gx0 += d[0]; gx1 += d[1]; gx2 += d[2]; gy0 += d[3]; gy1 += d[4]; gy2 += d[5];
+                }
+            }
+            if (cnt_x > 0 && cnt_y > 0) {
+                const double k = 1.0 / 4294967296.0;
+                const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
+                const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
+                const double n0 = GY1 * GX2 - GY2 * GX1;
+                const double n1 = GY2 * GX0 - GY0 * GX2;
+                const double n2 = GY0 * GX1 - GY1 * GX0;
+                const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
+                if (len2 != 0.0) {
+                    const float nz = (float)(n2 / sqrt(len2));
+                    if (nz == nz) out = acos_f32_dev(fabsf(nz));
+                }
+            }
+        }
+    }
+    nfeat_all[(size_t)frame * g.lw * g.lh + (size_t)ly_s * g.lw + lx_s] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
 void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
                  const float* d_calibA, uint32_t* d_lab, float4* d_cloud, int n, hipStream_t s) {
     LabCoeffs lc;
@@ -264,6 +347,14 @@ void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_rec
 
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
                            int n, hipStream_t s) {
+    const int tw = NF_TX * g.stride + 2 * NF_APRON, th = NF_TY * g.stride + 2 * NF_APRON;
+    const size_t lds = (size_t)tw * th * 49;
+    if (lds <= 64 * 1024) {
+        const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
+        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_TY * NF_TX), lds, s>>>(
+            g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y);
+        return;
+    }
     const int total = g.lw * g.lh * n;
     normal_feature_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, d_cloud, d_rect, d_nfeat, n);
 }

@@ -164,7 +164,7 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
     __syncthreads();
 
     // ---- phase B: Lab patch, cv::resize(ROI -> r x r) in 11-bit fixed point (feature_extractor.h:142)
-    if (g.n_patch > 0) {
+    if (g.n_patch > 0 && !(g.debug_skip & 1)) {
         const int rr = g.r * g.r;
         for (int k0 = 0; k0 < rr; k0 += 64) {
             const int k = k0 + lane;
@@ -174,13 +174,15 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
                 if (!s[0] || k >= rr) continue;
                 const int half = s[1], size = 2 * half + 1;
                 const int x0 = s[2] - half, y0 = s[3] - half;
-                const ResizeRow& row = rt[half];
-                const int sx0 = row.xofs[dx];
+                // one 8-byte record per axis: {source index, weight of it, weight of the next}
+                const uint2 xr = *reinterpret_cast<const uint2*>(&rt[half].x[dx]);
+                const uint2 yr = *reinterpret_cast<const uint2*>(&rt[half].y[dy]);
+                const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
+                const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
                 const int sx1 = sx0 + 1 < size ? sx0 + 1 : sx0;
-                int sy0 = row.yofs[dy], sy1 = sy0 + 1;
+                int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = sy0 + 1;
                 sy0 = sy0 < 0 ? 0 : (sy0 >= size ? size - 1 : sy0);
                 sy1 = sy1 < 0 ? 0 : (sy1 >= size ? size - 1 : sy1);
-                const int ia0 = row.ia0[dx], ia1 = row.ia1[dx], ib0 = row.ib0[dy], ib1 = row.ib1[dy];
                 const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
                 const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
                 const uint32_t* lab = lab_all + (size_t)s[7] * W * H;
@@ -228,7 +230,7 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
     const int4* np = reinterpret_cast<const int4*>(nodes);
     for (int t = sub; t < n_trees; t += 4) {
         int row = 0;
-        if (valid) {
+        if (valid && !(g.debug_skip & 2)) {
             int4 nd = np[roots[t]];
             while (nd.z != 0) {
                 const int f = nd.x;

@@ -19,16 +19,18 @@ struct FrameGeom {
     int pos_depth, pos_height, pos_normal; // index of each scalar feature in the vector or -1
     int D;                      // feature length
     float fill;                 // low-res image fill value
+    int debug_skip;             // RVSEG_DEBUG_SKIP (timing experiments only): 1 = no patch, 2 = no traversal
 };
 
 struct LabCoeffs { int c[9]; };
 
 // cv::resize coefficient tables of the 8-bit patch path, one row per ROI half size
 // (size = 2*half+1), host-computed with the formula the oracle states (OpenCV 2.4 imgwarp.cpp).
-constexpr int RT_MAXR = 32;
+constexpr int RT_MAXR = 16;
+struct ResizeRec { int16_t ofs, w0, w1, pad; };   // source index, 11-bit weights of (ofs, ofs+1)
 struct ResizeRow {
-    int16_t xofs[RT_MAXR], ia0[RT_MAXR], ia1[RT_MAXR];
-    int16_t yofs[RT_MAXR], ib0[RT_MAXR], ib1[RT_MAXR];
+    ResizeRec x[RT_MAXR];   // x axis: weights clamped at the ROI border
+    ResizeRec y[RT_MAXR];   // y axis: weights kept, rows clipped by the caller
 };
 
 // float up-sampling tables (cv::resize INTER_LINEAR on CV_32FC(n), segmenter.cpp:380-382)

@@ -2,6 +2,7 @@
 // (replaces the body of Segmenter::processFramesFromQueueInternalRF, src/segmenter.cpp:351-431,
 // and -- with use_dense_crf -- the DenseCRF call shape of src/segmenter.cpp:639-657 per frame).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "rvseg_internal.h"
@@ -60,6 +61,7 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
     g.pos_normal = p.feature_normal ? pos++ : -1;
     g.D = pos;
     g.fill = p.fill_value;
+    g.debug_skip = std::getenv("RVSEG_DEBUG_SKIP") ? std::atoi(std::getenv("RVSEG_DEBUG_SKIP")) : 0;
 
     rvseg_status st;
     // 8-bit patch resize tables, one row per ROI half size
@@ -73,15 +75,15 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
             std::memset(&rr, 0, sizeof(rr));
             resize_coeffs(size, g.r, true, ofs, w0, w1);
             for (int d = 0; d < g.r; d++) {
-                rr.xofs[d] = (int16_t)ofs[d];
-                rr.ia0[d] = (int16_t)std::lrintf(w0[d] * 2048.f);  // saturate_cast<short>: round half to even
-                rr.ia1[d] = (int16_t)std::lrintf(w1[d] * 2048.f);
+                rr.x[d].ofs = (int16_t)ofs[d];
+                rr.x[d].w0 = (int16_t)std::lrintf(w0[d] * 2048.f);  // saturate_cast<short>: round half to even
+                rr.x[d].w1 = (int16_t)std::lrintf(w1[d] * 2048.f);
             }
             resize_coeffs(size, g.r, false, ofs, w0, w1);
             for (int d = 0; d < g.r; d++) {
-                rr.yofs[d] = (int16_t)ofs[d];
-                rr.ib0[d] = (int16_t)std::lrintf(w0[d] * 2048.f);
-                rr.ib1[d] = (int16_t)std::lrintf(w1[d] * 2048.f);
+                rr.y[d].ofs = (int16_t)ofs[d];
+                rr.y[d].w0 = (int16_t)std::lrintf(w0[d] * 2048.f);
+                rr.y[d].w1 = (int16_t)std::lrintf(w1[d] * 2048.f);
             }
         }
         if ((st = upload(ctx, im->resize_rows, rows.data(), rows.size() * sizeof(ResizeRow))) != RVSEG_OK) return st;
