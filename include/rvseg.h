@@ -88,7 +88,11 @@ typedef struct rvseg_params {
     int32_t max_batch;              /* frames processed per launch group (device buffers are sized
                                        for this many frames)                                        */
     int32_t device;                 /* HIP device ordinal                                           */
-    int32_t lattice_capacity_log2;  /* hash-table slots per frame = 2^this (0 = automatic)          */
+    int32_t lattice_capacity_log2;  /* hash-table slots per frame = 2^this; 0 = 2^12 (the Segmenter
+                                       kernel gives ~300 vertices / frame), -1 = worst case 2*N*(d+1).
+                                       Overflow is detected: host entry points retry with the worst
+                                       case, the _device entry point reports RVSEG_ERR_CAPACITY on the
+                                       next call                                                     */
 } rvseg_params;
 
 /* Fills *p with the defaults of resources/config.json. */

@@ -330,7 +330,8 @@ __global__ void __launch_bounds__(256)
 lattice_remap_kernel(LatticeDev L, unsigned* __restrict__ sort_keys, unsigned* __restrict__ sort_vals, long long n_entries) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_entries) return;
-    const int id = L.slot_to_id[L.offsets[e]];
+    int id = L.slot_to_id[L.offsets[e]];
+    id = id < L.m_bound ? id : L.m_bound - 1;   // only after a (flagged) hash overflow
     L.offsets[e] = id;
     sort_keys[e] = (unsigned)id;
     sort_vals[e] = (unsigned)e;
@@ -376,6 +377,161 @@ lattice_csr_kernel(LatticeDev L, const unsigned* __restrict__ keys_sorted, const
 
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// Vertex-major ordering by a counting sort (fast path, used when a frame has at most CS_MCAP
+// vertices -- the Segmenter kernel has ~300).  The entries of a frame are cut into wave-blocks of
+// CS_PIX points; every wave walks its block in order, 64 entries at a time, and ranks equal vertex
+// ids inside the chunk with ballots, so the order inside a vertex stays ascending in the point
+// index without any comparison sort:
+//   pass 1 (count)   per wave-block histogram over the frame's vertices (LDS) + slot -> id remap
+//   scan             per frame: vertex start offsets and per-(wave-block, vertex) bases
+//   pass 2 (scatter) same walk, entries land at base + rank
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_PIX = 256;
+constexpr int CS_MCAP = 2048;
+
+// bh holds, per frame, a dense [wave-block][vertex] matrix with row stride M_f; the frame's matrix
+// starts at wbpf * fstart[frame] (so the whole array needs wbpf * M_total words).
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
+    extern __shared__ unsigned cs_cnt[];   // [4 waves][mcap]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long gwb = (long long)blockIdx.x * 4 + wave;
+    const int frame = (int)(gwb / wbpf);
+    if (frame >= L.n_frames) return;       // whole wave; no block-wide barrier below
+    const int wb = (int)(gwb - (long long)frame * wbpf);
+    // (clamps only matter after a flagged hash overflow; they keep every access in bounds)
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const unsigned n_entries_total = (unsigned)((long long)L.n_frames * L.N * (L.d + 1));
+    unsigned* my = cs_cnt + (size_t)wave * mcap;
+    unsigned* row = bh + (size_t)wbpf * f0 + (size_t)wb * Mf;
+    for (int lv = lane; lv < Mf; lv += 64) my[lv] = SCATTER ? row[lv] : 0u;
+    if (Mf == 0 && lane == 0) my[0] = 0xFFFFFFFFu;   // no vertices (overflow only): positions fail the bound check
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int dp1 = L.d + 1;
+    const long long p0 = (long long)wb * CS_PIX;
+    const long long p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const long long ebeg = ((long long)frame * L.N + p0) * dp1, eend = ((long long)frame * L.N + p1) * dp1;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // software pipeline: the next chunk's loads are in flight while the current chunk is ranked
+    auto fetch = [&](long long e, int& id, float& wgt) {
+        id = 0; wgt = 0.f;
+        if (e < eend) {
+            // ids beyond the per-vertex arrays only occur after a (flagged) hash overflow: clamp so that
+            // every later kernel stays in bounds; the host discards the result
+            if (!SCATTER) { id = L.slot_to_id[L.offsets[e]]; id = id < L.m_bound ? id : L.m_bound - 1; }
+            else { id = L.offsets[e]; wgt = L.bary[e]; }
+        }
+    };
+    int id_n; float w_n;
+    fetch(ebeg + lane, id_n, w_n);
+    for (long long base = ebeg; base < eend; base += 64) {
+        const long long e = base + lane;
+        const bool valid = e < eend;
+        const int id = id_n;
+        const float wgt = w_n;
+        fetch(e + 64, id_n, w_n);
+        if (!SCATTER && valid) L.offsets[e] = id;    // slot -> vertex id, in place
+        int lv = valid ? id - f0 : -1;
+        if (lv >= Mf) lv = Mf - 1;                   // overflow case (flagged elsewhere): stay in bounds
+        if (valid && lv < 0) lv = 0;
+        bool pending = valid;
+        // distinct vertex ids of a chunk touch distinct counters, so the loop needs no ordering
+        // inside a chunk; one fence per chunk orders the counters between chunks
+        for (;;) {
+            const unsigned long long todo = __ballot(pending);
+            if (!todo) break;
+            const int leader = __ffsll((long long)todo) - 1;
+            const int k = __shfl(lv, leader, 64);
+            const bool same = pending && lv == k;
+            const unsigned long long m = __ballot(same);
+            const unsigned c = (unsigned)__popcll(m);
+            if (SCATTER) {
+                const unsigned b = my[k];
+                if (same) {
+                    const unsigned pos = b + (unsigned)__popcll(m & lt);
+                    if (pos < n_entries_total) {
+                        L.csr_pix[pos] = (unsigned)(e / dp1);
+                        L.csr_w[pos] = wgt;
+                    }
+                }
+                if (lane == leader) my[k] = b + c;
+            } else {
+                if (lane == leader) my[k] = my[k] + c;
+            }
+            pending = pending && !same;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (!SCATTER) {
+        for (int lv = lane; lv < Mf; lv += 64) row[lv] = my[lv];
+    }
+}
+
+// per frame: bh[wb][lv] (counts) -> absolute base of (wave-block, vertex) in the csr arrays;
+// vstart / vend per vertex.  1024 threads = 16 wave-block segments x 64 vertices.
+__global__ void __launch_bounds__(1024)
+csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
+    __shared__ unsigned sseg[16][64];
+    __shared__ unsigned vbase[64];
+    __shared__ unsigned carry;
+    const int frame = blockIdx.x;
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const int lvl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int sw = (wbpf + 15) / 16;
+    const int w0 = seg * sw, w1 = (w0 + sw < wbpf) ? w0 + sw : wbpf;
+    unsigned* fb = bh + (size_t)wbpf * f0;   // dense [wave-block][vertex] matrix, row stride Mf
+    const unsigned frame_base = (unsigned)((long long)frame * L.N * (L.d + 1));
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int lv0 = 0; lv0 < Mf; lv0 += 64) {
+        const int lv = lv0 + lvl;
+        const bool ok = lv < Mf;
+        unsigned sum = 0;
+        if (ok) for (int w = w0; w < w1; w++) sum += fb[(size_t)w * Mf + lv];
+        sseg[seg][lvl] = sum;
+        __syncthreads();
+        unsigned pre = 0, total = 0;
+        for (int q = 0; q < 16; q++) { const unsigned t = sseg[q][lvl]; if (q < seg) pre += t; total += t; }
+        if (seg == 0) {
+            // exclusive scan of the 64 column totals (one wave)
+            unsigned incl = total;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off, 64);
+                if (lvl >= off) incl += t;
+            }
+            const unsigned c0 = carry;
+            vbase[lvl] = c0 + incl - total;
+            if (ok) {
+                L.vstart[f0 + lv] = frame_base + c0 + incl - total;
+                L.vend[f0 + lv] = frame_base + c0 + incl;
+            }
+            if (lvl == 63) carry = c0 + incl;
+        }
+        __syncthreads();
+        if (ok) {
+            unsigned run = frame_base + vbase[lvl] + pre;
+            for (int w = w0; w < w1; w++) {
+                const unsigned t = fb[(size_t)w * Mf + lv];
+                fb[(size_t)w * Mf + lv] = run;
+                run += t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool csr_fast_path(const LatticeDev& L) { return ((L.cap_f_mask + 1) / 2) <= (unsigned)CS_MCAP; }
+size_t csr_fast_bytes(const LatticeDev& L) {
+    const size_t wbpf = ((size_t)L.N + CS_PIX - 1) / CS_PIX;
+    return wbpf * ((size_t)L.m_bound + 64) * sizeof(unsigned);
+}
+
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
     const unsigned cap = L.cap_total;
     {
@@ -384,14 +540,25 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         (void)rocprim::exclusive_scan(sb.scan_temp, temp, in, L.slot_to_id, 0, (size_t)cap, rocprim::plus<int>(), s);
     }
     lattice_compact_kernel<<<dim3((cap + 255) / 256), dim3(256), 0, s>>>(L);
-    lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
     const long long nb_threads = (long long)L.m_bound * (L.d + 1);
     lattice_neighbours_kernel<<<dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, s>>>(L);
-    // stable radix sort by vertex id: equal keys keep ascending entry (= point) order
-    size_t temp = sb.temp_bytes;
-    (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
-                                    (unsigned)sb.key_bits, s);
-    lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+    if (csr_fast_path(L) && sb.block_hist) {
+        const int mcap = (int)((L.cap_f_mask + 1) / 2);
+        const int wbpf = (L.N + CS_PIX - 1) / CS_PIX;
+        const long long waves = (long long)wbpf * L.n_frames;
+        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
+        csr_pass_kernel<false><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
+        csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+    } else {
+        lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
+        // stable radix sort by vertex id: equal keys keep ascending entry (= point) order
+        size_t temp = sb.temp_bytes;
+        (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
+                                        (unsigned)sb.key_bits, s);
+        lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+    }
     launch_vertex_order(L, sb, s);
 }
 
@@ -440,13 +607,15 @@ size_t sort_temp_bytes(long long n_entries, int key_bits) {
 
 // norm values gathered into CSR order once the normaliser exists
 __global__ void __launch_bounds__(256)
-csr_norm_kernel(const unsigned* __restrict__ csr_pix, const float* __restrict__ norm, float* __restrict__ csr_nrm, long long n_entries) {
+csr_norm_kernel(const unsigned* __restrict__ csr_pix, const float* __restrict__ norm, float* __restrict__ csr_nrm, long long n_entries,
+                const int* __restrict__ counters) {
+    if (counters[1]) return;   // hash overflow (flagged): csr_pix is incomplete
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_entries) csr_nrm[k] = norm[csr_pix[k]];
 }
 
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
-    csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pix, L.norm, L.csr_nrm, n_entries);
+    csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pix, L.norm, L.csr_nrm, n_entries, L.counters);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -468,6 +637,7 @@ template <int MODE, int CC>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2
 __global__ void __launch_bounds__(64)
 splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
     __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
+    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
     // block b -> group b % G (= the XCD it lands on when G == 8), rank b / G inside the group
     const unsigned g = blockIdx.x % (unsigned)L.n_groups, j = blockIdx.x / (unsigned)L.n_groups;
     if (j >= L.gcount[g]) return;
@@ -574,6 +744,7 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
 template <bool SEQ>
 __global__ void __launch_bounds__(256)
 blur_kernel(LatticeDev L, int axis, int C, const float* __restrict__ old_v, float* __restrict__ new_v) {
+    if (L.counters[1]) return;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
     if (gid >= (long long)M * C) return;
@@ -615,6 +786,7 @@ template <bool SEQ, int OUT_MODE>
 __global__ void __launch_bounds__(256)
 slice_kernel(LatticeDev L, int C, const float* __restrict__ values, float alpha, float neg_w, float* __restrict__ out,
              long long n_points) {
+    if (L.counters[1]) return;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_points * C) return;
     const long long p = gid / C;
@@ -717,6 +889,7 @@ __global__ void __launch_bounds__(256)
 mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float neg_w, ValueView unary, int negate,
                  ValueView Q) {
     extern __shared__ __attribute__((aligned(16))) float tab[];
+    if (L.counters[1]) return;   // uniform: hash overflow (flagged)
     constexpr int CP = (C + 3) / 4 * 4;
     const int bpf = (L.N + 255) / 256;
     const int frame = blockIdx.x / bpf;

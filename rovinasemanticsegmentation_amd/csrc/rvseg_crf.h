@@ -70,6 +70,7 @@ struct SortBuffers {
     int key_bits;
     void* scan_temp;
     size_t scan_temp_bytes;
+    unsigned* block_hist;   // counting-sort fast path: n_frames x wave-blocks x (cap_f/2), or null
 };
 
 void launch_fill_int(int* p, int v, long long n, hipStream_t s);
@@ -77,6 +78,8 @@ void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStre
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s);
 size_t sort_temp_bytes(long long n_entries, int key_bits);
 size_t scan_temp_bytes(unsigned cap);
+bool csr_fast_path(const LatticeDev& L);
+size_t csr_fast_bytes(const LatticeDev& L);
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s);

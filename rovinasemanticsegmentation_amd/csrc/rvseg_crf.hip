@@ -2,6 +2,8 @@
 // rvseg_crf_infer / rvseg_crf_infer_multi / rvseg_lattice_build / rvseg_lattice_filter and the
 // per-frame CRF stage of the frame pipeline.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "rvseg_crf.h"
@@ -11,7 +13,7 @@ namespace rvseg {
 
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pix, csr_w, csr_nrm, vstart, vend, norm;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount, block_hist;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -38,7 +40,7 @@ static CrfState* crf_state(Pipeline* im) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pix, &b.csr_w, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount, &b.block_hist};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -65,7 +67,7 @@ static int capacity_log2_per_frame(const rvseg_ctx* ctx, int Npad, int d, bool s
     const int safe_log2 = ceil_log2(2ull * (unsigned long long)Npad * (d + 1));
     int want = ctx->params.lattice_capacity_log2;
     if (safe || want < 0) return safe_log2;
-    if (want == 0) want = 18;
+    if (want == 0) want = 12;   // the Segmenter kernel yields ~300 vertices per 640x480 frame
     return want < safe_log2 ? want : safe_log2;
 }
 
@@ -138,6 +140,11 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
     b.sb.scan_temp = b.scan_temp.p; b.sb.scan_temp_bytes = stemp;
+    b.sb.block_hist = nullptr;
+    if (csr_fast_path(L)) {
+        if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
+        b.sb.block_hist = b.block_hist.as<unsigned>();
+    }
     b.n_entries = E; b.n_points = P;
     b.built = false;
     return RVSEG_OK;
@@ -157,8 +164,17 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
     RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
     RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
+    const bool trace = std::getenv("RVSEG_TRACE") != nullptr;
+    auto tr = [&](const char* what) {
+        if (!trace) return;
+        hipError_t e = hipStreamSynchronize(s);
+        std::fprintf(stderr, "[rvseg] %s: %s (N=%d d=%d cap_f=%u m_bound=%d)\n", what, hipGetErrorString(e), L.N, L.d, L.cap_f_mask + 1, L.m_bound);
+    };
+    tr("memsets");
     launch_lattice_points(L, fs, s);
+    tr("points");
     launch_lattice_finish(L, b.sb, b.n_entries, s);
+    tr("finish");
     rvseg_status st = values_reserve(ctx, cs, L.m_bound, 1);
     if (st != RVSEG_OK) return st;
     // norm = lattice.compute(ones) through seqCompute (1 row), then 1/sqrt(norm + 1e-20)
@@ -167,6 +183,7 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
     launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
     launch_csr_norm(L, b.n_entries, s);
+    tr("normaliser");
     RV_HIP(ctx, hipGetLastError());
     b.built = true;
     return RVSEG_OK;
