@@ -67,6 +67,50 @@ __device__ __forceinline__ float exp_f32_dev(float xf) {
     return (float)(p * scale);
 }
 
+// Rows of C floats / d+1 ints are only 4-byte aligned; these vector types let the compiler fetch
+// them with dwordx4 / dwordx2 instructions (global memory tolerates dword-aligned wide accesses),
+// i.e. ceil(C/4) vector-memory requests per lane instead of C.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef int i32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int N, typename T>
+__device__ __forceinline__ void load_row(const T* __restrict__ p, T* __restrict__ out) {
+    typedef T v4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef T v2 __attribute__((ext_vector_type(2), aligned(4)));
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= N; i += 4) {
+        const v4 t = *reinterpret_cast<const v4*>(p + i);
+        out[i] = t.x; out[i + 1] = t.y; out[i + 2] = t.z; out[i + 3] = t.w;
+    }
+    if (i + 2 <= N) {
+        const v2 t = *reinterpret_cast<const v2*>(p + i);
+        out[i] = t.x; out[i + 1] = t.y;
+        i += 2;
+    }
+    if (i < N) out[i] = p[i];
+}
+
+template <int N, typename T>
+__device__ __forceinline__ void store_row(T* __restrict__ p, const T* __restrict__ in) {
+    typedef T v4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef T v2 __attribute__((ext_vector_type(2), aligned(4)));
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= N; i += 4) {
+        v4 t; t.x = in[i]; t.y = in[i + 1]; t.z = in[i + 2]; t.w = in[i + 3];
+        *reinterpret_cast<v4*>(p + i) = t;
+    }
+    if (i + 2 <= N) {
+        v2 t; t.x = in[i]; t.y = in[i + 1];
+        *reinterpret_cast<v2*>(p + i) = t;
+        i += 2;
+    }
+    if (i < N) p[i] = in[i];
+}
+
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
 }  // namespace rvseg

@@ -526,6 +526,56 @@ csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     }
 }
 
+// Range-major variant of the scan.  The frame is cut into ranges of L.range_wb wave-blocks; the
+// csr arrays are ordered (range, vertex, point), so that a vertex's entries inside one range (a
+// "piece") are contiguous.  The ordered splat then advances range by range (one launch per range):
+// all readers of a range's Q rows run together and share them in L2, and a vertex's running sum
+// is carried from piece to piece through `values`.  Every range holds exactly
+// range_wb * CS_PIX * (d+1) entries, so range bases are known without a scan.
+// One wave owns the ranges r = wave, wave+16, ...; no block-level synchronisation is needed.
+__global__ void __launch_bounds__(1024)
+csr_scan_range_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
+    const int frame = blockIdx.x;
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const int lvl = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned* fb = bh + (size_t)wbpf * f0;
+    const int grp = frame % L.n_groups;
+    const unsigned frame_base = (unsigned)((long long)frame * L.N * (L.d + 1));
+    const unsigned range_entries = (unsigned)L.range_wb * CS_PIX * (unsigned)(L.d + 1);
+    for (int r = wave; r < L.n_ranges; r += 16) {
+        const int w0 = r * L.range_wb, w1 = (w0 + L.range_wb < wbpf) ? w0 + L.range_wb : wbpf;
+        unsigned carry = 0;   // entries of the range taken by vertices below the current chunk
+        for (int lv0 = 0; lv0 < Mf; lv0 += 64) {
+            const int lv = lv0 + lvl;
+            const bool ok = lv < Mf;
+            unsigned cnt = 0;
+            if (ok) for (int w = w0; w < w1; w++) cnt += fb[(size_t)w * Mf + lv];
+            unsigned incl = cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(incl, off, 64);
+                if (lvl >= off) incl += t;
+            }
+            const unsigned start = frame_base + (unsigned)r * range_entries + carry + incl - cnt;
+            if (ok) {
+                if (cnt > 0) {   // non-empty piece: append to the (range, frame group) work list
+                    const unsigned li = (unsigned)(r * L.n_groups + grp);
+                    const unsigned slot = atomicAdd(L.pcount + li, 1u);
+                    if (slot < L.pcap) L.plist[(size_t)li * L.pcap + slot] = make_uint4((unsigned)(f0 + lv), start, cnt, 0u);
+                }
+                unsigned run = start;
+                for (int w = w0; w < w1; w++) {
+                    const unsigned t = fb[(size_t)w * Mf + lv];
+                    fb[(size_t)w * Mf + lv] = run;
+                    run += t;
+                }
+            }
+            carry += __shfl(incl, 63, 64);
+        }
+    }
+}
+
 bool csr_fast_path(const LatticeDev& L) { return ((L.cap_f_mask + 1) / 2) <= (unsigned)CS_MCAP; }
 size_t csr_fast_bytes(const LatticeDev& L) {
     const size_t wbpf = ((size_t)L.N + CS_PIX - 1) / CS_PIX;
@@ -549,7 +599,8 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
         csr_pass_kernel<false><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
+        if (L.range_mode) csr_scan_range_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
+        else csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
         csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
     } else {
         lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
@@ -559,7 +610,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
                                         (unsigned)sb.key_bits, s);
         lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
     }
-    launch_vertex_order(L, sb, s);
+    if (!L.range_mode) launch_vertex_order(L, sb, s);
 }
 
 // Launch order of the vertices for the splat: grouped by (frame mod G) so that, with the
@@ -633,25 +684,43 @@ constexpr int SPLAT_R = 4;    // register ring: entries are loaded 3 tiles ahead
 // CC = classes handled by this pass (compile time, so the body is branch-free and the compiler
 // keeps counted vmcnt waits); classes [c0, c0 + n_store) are stored, n_store <= CC; lanes of the
 // padding classes re-read class c0 + n_store - 1 and drop the result.
-template <int MODE, int CC>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
+// RANGE = false: one launch, a block sums a vertex's whole list.
+// RANGE = true : launch `range` of n_ranges; a block sums the vertex's piece inside that range and
+//                carries the running sum in `values` (zeroed by the caller before range 0).
+template <int MODE, int CC, bool RANGE>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
 __global__ void __launch_bounds__(64)
-splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
+splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int range) {
     __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
-    // block b -> group b % G (= the XCD it lands on when G == 8), rank b / G inside the group
-    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j = blockIdx.x / (unsigned)L.n_groups;
-    if (j >= L.gcount[g]) return;
-    unsigned gstart = 0;
-    for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
-    const int v = (int)L.vorder[gstart + j];
     const int lane = threadIdx.x;
-    const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+    // block b -> group b % G (= the XCD it lands on when G == 8), rank b / G inside the group
+    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j0 = blockIdx.x / (unsigned)L.n_groups;
+    const unsigned jstep = gridDim.x / (unsigned)L.n_groups;
+    unsigned n_items, gstart = 0;
+    if (RANGE) {
+        n_items = L.pcount[range * L.n_groups + g];
+        n_items = n_items < L.pcap ? n_items : L.pcap;
+    } else {
+        n_items = L.gcount[g];
+        for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
+    }
+  for (unsigned j = j0; j < n_items; j += jstep) {   // RANGE: a block may own several pieces of this range
+    int v;
+    unsigned k0, k1;
+    if (RANGE) {
+        const uint4 pc = L.plist[(size_t)(range * L.n_groups + g) * L.pcap + j];
+        v = (int)pc.x; k0 = pc.y; k1 = pc.y + pc.z;
+    } else {
+        v = (int)L.vorder[gstart + j];
+        k0 = L.vstart[v]; k1 = L.vend[v];
+    }
     const unsigned n_tiles = (k1 - k0 + 63u) / 64u;
     if (n_tiles == 0) {  // vertex created by a padding lane only: no mass
         if (lane < n_store) values[(size_t)v * C + c0 + lane] = 0.0f;
-        return;
+        continue;
     }
     float acc = 0.0f;
+    if (RANGE && lane < n_store) acc = values[(size_t)v * C + c0 + lane];   // carry from the earlier ranges
     float x[SPLAT_R][CC];
     float w[SPLAT_R], nrm[SPLAT_R];
     unsigned pix[SPLAT_R];
@@ -670,73 +739,101 @@ splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, flo
     auto gather_rows = [&](int slot) {
         if (MODE == 2) return;
         const size_t row = src.index(pix[slot], c0, C, L.N);
+        if (n_store == CC) {
+            load_row<CC>(src.base + row, x[slot]);   // ceil(CC/4) wide requests per lane
+        } else {
 #pragma unroll
-        for (int c = 0; c < CC; c++) x[slot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+            for (int c = 0; c < CC; c++) x[slot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+        }
     };
     // prologue: entries of tiles 0..2, rows of tiles 0..1
     load_entries(0, 0); load_entries(1, 1); load_entries(2, 2);
     gather_rows(0); gather_rows(1);
 
-    for (unsigned t0 = 0; t0 < n_tiles; t0 += SPLAT_R) {
+    bool more = true;
+    for (unsigned t0 = 0; more; t0 += SPLAT_R) {
 #pragma unroll
         for (int s = 0; s < SPLAT_R; s++) {
             const unsigned t = t0 + s;
-            if (t < n_tiles) {   // uniform across the wave
+            // `break`, not `if`: a later stage must never be reachable past a skipped earlier one, or
+            // the compiler has to assume that path and drains the load queue (vmcnt(0)) in every stage
+            if (t >= n_tiles) { more = false; break; }
+            {
                 const unsigned base = k0 + t * 64u;
                 const unsigned n_valid = k1 - base < 64u ? k1 - base : 64u;
+                // lanes beyond the list park +0.0f: the running sum starts at +0 and can never become -0,
+                // so adding +0 is the identity and every tile can run the same 64 adds (no tail branch)
+                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
 #pragma unroll
                 for (int c = 0; c < CC; c++) {
                     float xin = MODE == 2 ? 1.0f : x[s][c];
                     if (MODE == 1) xin = xin * nrm[s];
-                    prod[c][lane] = w[s] * xin;   // lanes >= n_valid hold a clamped duplicate, never added
+                    const float pr = wl * xin;
+                    prod[c][lane] = (unsigned)lane < n_valid ? pr : 0.0f;
                 }
                 __syncthreads();
                 // keep the memory pipeline full while the dependent adds below run
                 load_entries(t + 3, (s + 3) % SPLAT_R);
                 gather_rows((s + 2) % SPLAT_R);
-                if (lane < CC) {
-                    const float* pr = prod[lane];
-                    if (n_valid == 64u) {
-                        // all 16 quad reads are issued before the first add: one LDS round trip per
-                        // tile; the adds stay strictly in list order
-                        float4 q[16];
+                {
+                    // all 16 quad reads are issued before the first add: one LDS round trip per tile;
+                    // the adds stay strictly in list order.  Lanes >= CC compute on row 0 and are ignored
+                    // (no divergent branch, so the memory waits stay counted).
+                    const float* pr = prod[lane < CC ? lane : 0];
+                    float4 q[16];
 #pragma unroll
-                        for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+                    for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
 #pragma unroll
-                        for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
-                    } else {
-                        for (unsigned k = 0; k < n_valid; k++) acc += pr[k];
-                    }
+                    for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
                 }
                 __syncthreads();
             }
         }
     }
     if (lane < n_store) values[(size_t)v * C + c0 + lane] = acc;
+  }
 }
 
-template <int MODE>
-static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
-    const dim3 grid((unsigned)L.splat_grid), block(64);
-    if (n == 1) splat_gather_kernel<MODE, 1><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else if (n == 2) splat_gather_kernel<MODE, 2><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else if (n <= 4) splat_gather_kernel<MODE, 4><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else if (n <= 8) splat_gather_kernel<MODE, 8><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else if (n == 9) splat_gather_kernel<MODE, 9><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else splat_gather_kernel<MODE, 16><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+template <int MODE, bool RANGE>
+static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, int range, hipStream_t s) {
+    const dim3 grid(RANGE ? L.range_grid : L.splat_grid), block(64);
+    if (n == 1) splat_gather_kernel<MODE, 1, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
+    else if (n == 2) splat_gather_kernel<MODE, 2, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
+    else if (n <= 4) splat_gather_kernel<MODE, 4, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
+    else if (n <= 8) splat_gather_kernel<MODE, 8, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
+    else if (n == 9) splat_gather_kernel<MODE, 9, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
+    else splat_gather_kernel<MODE, 16, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
 }
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
+    if (L.range_mode) {
+        // running sums start at zero; vertices without entries keep it
+        (void)hipMemsetAsync(values, 0, (size_t)L.m_bound * (mode == 2 ? 1 : C) * sizeof(float), s);
+        for (int r = 0; r < L.n_ranges; r++) {
+            if (mode == 2) {
+                splat_gather_kernel<2, 1, true><<<dim3(L.range_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, r);
+                continue;
+            }
+            for (int c0 = 0; c0 < C; c0 += 16) {
+                const int n = C - c0 < 16 ? C - c0 : 16;
+                if (mode == 0) splat_pass<0, true>(L, src, C, c0, n, values, r, s);
+                else splat_pass<1, true>(L, src, C, c0, n, values, r, s);
+            }
+        }
+        return;
+    }
     if (mode == 2) {
-        splat_gather_kernel<2, 1><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values);
+        splat_gather_kernel<2, 1, false><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, 0);
         return;
     }
     for (int c0 = 0; c0 < C; c0 += 16) {
         const int n = C - c0 < 16 ? C - c0 : 16;
-        if (mode == 0) splat_pass<0>(L, src, C, c0, n, values, s);
-        else splat_pass<1>(L, src, C, c0, n, values, s);
+        if (mode == 0) splat_pass<0, false>(L, src, C, c0, n, values, 0, s);
+        else splat_pass<1, false>(L, src, C, c0, n, values, 0, s);
     }
 }
+
+int csr_pix_per_block() { return CS_PIX; }
 
 // ---------------------------------------------------------------------------------------------
 // blur along one lattice axis (permutohedral.cpp:556-569 / :496-510)
@@ -884,7 +981,7 @@ void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long lon
 // ---------------------------------------------------------------------------------------------
 constexpr int MF_LDS_BYTES = 48 * 1024;
 
-template <bool SEQ, int C>
+template <bool SEQ, int C, int DP1>   // DP1 = d+1 at compile time (wide offset / weight loads), 0 = runtime d
 __global__ void __launch_bounds__(256)
 mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float neg_w, ValueView unary, int negate,
                  ValueView Q) {
@@ -906,22 +1003,28 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     }
     if (i >= L.N) return;
     const size_t p = (size_t)frame * L.N + i;
-    const int dp1 = L.d + 1;
+    const int dp1 = DP1 > 0 ? DP1 : L.d + 1;
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; c++) acc[c] = 0.0f;
-    for (int j = 0; j < dp1; j++) {
-        const int o = L.offsets[p * dp1 + j];
-        const float bw = L.bary[p * dp1 + j];
+    int offs[DP1 > 0 ? DP1 : 1];
+    float wts[DP1 > 0 ? DP1 : 1];
+    if (DP1 > 0) {
+        load_row<(DP1 > 0 ? DP1 : 1)>(L.offsets + p * dp1, offs);
+        load_row<(DP1 > 0 ? DP1 : 1)>(L.bary + p * dp1, wts);
+    }
+#pragma unroll
+    for (int j = 0; j < (DP1 > 0 ? DP1 : 8); j++) {
+        if (DP1 == 0 && j >= dp1) break;
+        const int o = DP1 > 0 ? offs[j] : L.offsets[p * dp1 + j];
+        const float bw = DP1 > 0 ? wts[j] : L.bary[p * dp1 + j];
         float val[C];
         if (use_lds) {
             const float* row = tab + (o - f0) * CP;
 #pragma unroll
             for (int c = 0; c < C; c++) val[c] = row[c];
         } else {
-            const float* row = values + (size_t)o * C;
-#pragma unroll
-            for (int c = 0; c < C; c++) val[c] = row[c];
+            load_row<C>(values + (size_t)o * C, val);
         }
         if (SEQ) {
 #pragma unroll
@@ -934,13 +1037,14 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     }
     const float nrm = L.norm[p];
     const size_t urow = unary.index((unsigned)p, 0, C, L.N);
-    float b[C];
+    float b[C], ur[C];
     float mx;
+    load_row<C>(unary.base + urow, ur);
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const float t = acc[c] * nrm;
         const float m = neg_w * t;
-        const float u = unary.base[urow + c];
+        const float u = ur[c];
         b[c] = (negate ? -u : u) - m;
     }
     mx = b[0];
@@ -951,7 +1055,8 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
     const size_t qrow = Q.index((unsigned)p, 0, C, L.N);
 #pragma unroll
-    for (int c = 0; c < C; c++) Q.base[qrow + c] = b[c] / sum;
+    for (int c = 0; c < C; c++) b[c] = b[c] / sum;
+    store_row<C>(Q.base + qrow, b);
 }
 
 // returns false when C has no fused instantiation (the caller then runs the unfused kernels)
@@ -960,7 +1065,10 @@ bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg
     const float alpha = 1.0f / (1 + powf(2, (float)-L.d));
     const int bpf = (L.N + 255) / 256;
     const dim3 grid((unsigned)(bpf * L.n_frames)), block(256);
-#define RV_MF(SEQ, CC) mf_update_kernel<SEQ, CC><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q); return true
+#define RV_MF(SEQ, CC)                                                                                            \
+    if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q); \
+    else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q);       \
+    return true
     switch (C) {
         case 2: RV_MF(true, 2);
         case 3: RV_MF(false, 3);

@@ -36,6 +36,14 @@ struct LatticeDev {
     unsigned* gcount;            // vertices per group (8 counters)
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
     unsigned splat_grid;         // n_groups * (largest possible group)
+    // range mode (large frames on the counting-sort path): csr order (range, vertex, point)
+    int range_mode;              // 1: splat advances range by range, carrying sums in `values`
+    int range_wb;                // wave-blocks (of CS_PIX points) per range
+    int n_ranges;
+    unsigned range_grid;         // blocks per range launch
+    uint4* plist;                // per (range, frame group): non-empty pieces {vertex, start, length, -}
+    unsigned* pcount;            // per (range, frame group): number of pieces
+    unsigned pcap;               // capacity of one piece list
     float* norm;                 // per point, pairwise.cpp:55-56
 };
 
@@ -80,6 +88,7 @@ size_t sort_temp_bytes(long long n_entries, int key_bits);
 size_t scan_temp_bytes(unsigned cap);
 bool csr_fast_path(const LatticeDev& L);
 size_t csr_fast_bytes(const LatticeDev& L);
+int csr_pix_per_block();
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s);
