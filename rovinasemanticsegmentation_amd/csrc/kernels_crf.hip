@@ -267,12 +267,14 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
     }
     __syncthreads();
     if (real) {
+        int so[D + 1];
 #pragma unroll
         for (int r = 0; r <= D; r++) {
             const int li = lidx[r];
-            L.offsets[gp * (D + 1) + r] = li >= 0 ? (int)lslot[li] : -1 - li;
-            L.bary[gp * (D + 1) + r] = bary[r];
+            so[r] = li >= 0 ? (int)lslot[li] : -1 - li;
         }
+        store_row<D + 1>(L.offsets + gp * (D + 1), so);
+        store_row<D + 1>(L.bary + gp * (D + 1), bary);
     }
 }
 
@@ -1095,8 +1097,9 @@ softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long 
     if (p >= n_points) return;
     const size_t urow = unary.index((unsigned)p, 0, C, N);
     float b[C];
+    load_row<C>(unary.base + urow, b);
 #pragma unroll
-    for (int c = 0; c < C; c++) { const float u = unary.base[urow + c]; b[c] = negate ? -u : u; }
+    for (int c = 0; c < C; c++) b[c] = negate ? -b[c] : b[c];
     float mx = b[0];
 #pragma unroll
     for (int c = 1; c < C; c++) if (b[c] > mx) mx = b[c];
@@ -1105,7 +1108,8 @@ softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long 
     for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
     const size_t qrow = q.index((unsigned)p, 0, C, N);
 #pragma unroll
-    for (int c = 0; c < C; c++) q.base[qrow + c] = b[c] / sum;
+    for (int c = 0; c < C; c++) b[c] = b[c] / sum;
+    store_row<C>(q.base + qrow, b);
 }
 
 bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {

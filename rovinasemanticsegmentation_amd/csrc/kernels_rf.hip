@@ -7,6 +7,7 @@
 // The node array is the breadth-first re-layout built by forest_model.cpp: 16-byte nodes, one
 // dwordx4 load per visited node, the hot top levels of every tree packed at the front of each
 // tree's block so that they stay in L1/L2.
+#include "device_math.h"
 #include "rvseg_internal.h"
 #include "rvseg_kernels.h"
 
@@ -186,8 +187,15 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
                 const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
                 const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
                 const uint32_t* lab = lab_all + (size_t)s[7] * W * H;
-                const uint32_t p00 = lab[(size_t)ry0 * W + rx0], p01 = lab[(size_t)ry0 * W + rx1];
-                const uint32_t p10 = lab[(size_t)ry1 * W + rx0], p11 = lab[(size_t)ry1 * W + rx1];
+                // the two taps of a row are always at most one pixel apart (also across the mirrored
+                // border): fetch them with one 8-byte load and pick
+                int xb = rx0 < rx1 ? rx0 : rx1;
+                xb = xb < W - 1 ? xb : W - 2;
+                typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+                const u32x2_u q0 = *reinterpret_cast<const u32x2_u*>(lab + (size_t)ry0 * W + xb);
+                const u32x2_u q1 = *reinterpret_cast<const u32x2_u*>(lab + (size_t)ry1 * W + xb);
+                const uint32_t p00 = rx0 == xb ? q0.x : q0.y, p01 = rx1 == xb ? q0.x : q0.y;
+                const uint32_t p10 = rx0 == xb ? q1.x : q1.y, p11 = rx1 == xb ? q1.x : q1.y;
                 unsigned char* dst = fb + pt * fb_stride + k * 3;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -304,10 +312,48 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
 
 // =============================================================================================
 // cv::resize(result, Size(W,H)) INTER_LINEAR on CV_32FC(C) + pack (segmenter.cpp:380-431).
-// One thread per output float so that stores are fully coalesced.
+// One thread per output pixel, all C classes of the layer in registers: four low-res rows in
+// (wide dword-aligned loads), one full-res row out.
 // =============================================================================================
+template <int C>
 __global__ void __launch_bounds__(256)
-upsample_pack_kernel(int W, int H, int lw, int lh, int C, size_t low_frame_stride, size_t low_layer_off,
+upsample_pack_kernel(int W, int H, int lw, int lh, size_t low_frame_stride, size_t low_layer_off,
+                     size_t post_frame_stride, size_t post_layer_off, const int* __restrict__ xofs,
+                     const float* __restrict__ ax0, const float* __restrict__ ax1, const int* __restrict__ yofs,
+                     const float* __restrict__ ay0, const float* __restrict__ ay1, const float* __restrict__ low_all,
+                     float* __restrict__ post_all, size_t total_pixels) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_pixels) return;
+    const size_t per_frame = (size_t)W * H;
+    const int frame = (int)(gid / per_frame);
+    const int pix = (int)(gid - (size_t)frame * per_frame);
+    const int y = pix / W, x = pix - y * W;
+    const float* low = low_all + (size_t)frame * low_frame_stride + low_layer_off;
+    int sy0 = yofs[y], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= lh ? lh - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= lh ? lh - 1 : sy1);
+    const int sx0 = xofs[x];
+    const bool tail = sx0 + 1 >= lw;   // dx >= xmax: D = S[sx]*ONE
+    const int sx1 = tail ? sx0 : sx0 + 1;
+    float s00[C], s01[C], s10[C], s11[C], o[C];
+    load_row<C>(low + ((size_t)sy0 * lw + sx0) * C, s00);
+    load_row<C>(low + ((size_t)sy0 * lw + sx1) * C, s01);
+    load_row<C>(low + ((size_t)sy1 * lw + sx0) * C, s10);
+    load_row<C>(low + ((size_t)sy1 * lw + sx1) * C, s11);
+    const float a0 = ax0[x], a1 = ax1[x], b0 = ay0[y], b1 = ay1[y];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        float h0, h1;
+        if (tail) { h0 = s00[c] * 1.f; h1 = s10[c] * 1.f; }
+        else { h0 = s00[c] * a0 + s01[c] * a1; h1 = s10[c] * a0 + s11[c] * a1; }
+        o[c] = h0 * b0 + h1 * b1;
+    }
+    store_row<C>(post_all + (size_t)frame * post_frame_stride + post_layer_off + (size_t)pix * C, o);
+}
+
+// generic class count: one thread per output float
+__global__ void __launch_bounds__(256)
+upsample_pack_generic_kernel(int W, int H, int lw, int lh, int C, size_t low_frame_stride, size_t low_layer_off,
                      size_t post_frame_stride, size_t post_layer_off, const int* __restrict__ xofs,
                      const float* __restrict__ ax0, const float* __restrict__ ax1, const int* __restrict__ yofs,
                      const float* __restrict__ ay0, const float* __restrict__ ay1, const float* __restrict__ low_all,
@@ -346,11 +392,26 @@ void launch_upsample_pack(const FrameGeom& g, const DeviceForest& f, const Upsam
     int prefix = 0;
     for (int l = 0; l < f.n_layers; l++) {
         const int C = f.class_counts[l];
-        const size_t total = (size_t)g.W * g.H * C * n;
-        upsample_pack_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-            g.W, g.H, g.lw, g.lh, C, low_frame, (size_t)g.lw * g.lh * prefix, post_frame, (size_t)g.W * g.H * prefix,
-            t.xofs.as<int>(), t.ax0.as<float>(), t.ax1.as<float>(), t.yofs.as<int>(), t.ay0.as<float>(), t.ay1.as<float>(),
-            d_low, d_post, total);
+        const size_t pixels = (size_t)g.W * g.H * n;
+        const dim3 pgrid((unsigned)((pixels + 255) / 256)), block(256);
+#define RV_UP(CC)                                                                                                        \
+    upsample_pack_kernel<CC><<<pgrid, block, 0, s>>>(g.W, g.H, g.lw, g.lh, low_frame, (size_t)g.lw * g.lh * prefix, post_frame, \
+                                                     (size_t)g.W * g.H * prefix, t.xofs.as<int>(), t.ax0.as<float>(),          \
+                                                     t.ax1.as<float>(), t.yofs.as<int>(), t.ay0.as<float>(), t.ay1.as<float>(), \
+                                                     d_low, d_post, pixels)
+        switch (C) {
+            case 2: RV_UP(2); break; case 3: RV_UP(3); break; case 4: RV_UP(4); break; case 5: RV_UP(5); break;
+            case 6: RV_UP(6); break; case 7: RV_UP(7); break; case 8: RV_UP(8); break; case 9: RV_UP(9); break;
+            case 10: RV_UP(10); break; case 12: RV_UP(12); break; case 16: RV_UP(16); break;
+            default: {
+                const size_t total = pixels * C;
+                upsample_pack_generic_kernel<<<dim3((unsigned)((total + 255) / 256)), block, 0, s>>>(
+                    g.W, g.H, g.lw, g.lh, C, low_frame, (size_t)g.lw * g.lh * prefix, post_frame, (size_t)g.W * g.H * prefix,
+                    t.xofs.as<int>(), t.ax0.as<float>(), t.ax1.as<float>(), t.yofs.as<int>(), t.ay0.as<float>(), t.ay1.as<float>(),
+                    d_low, d_post, total);
+            }
+        }
+#undef RV_UP
         prefix += C;
     }
 }
