@@ -371,8 +371,7 @@ lattice_csr_kernel(LatticeDev L, const unsigned* __restrict__ keys_sorted, const
     if (k >= n_entries) return;
     const unsigned e = vals_sorted[k];
     const unsigned key = keys_sorted[k];
-    L.csr_pix[k] = e / (unsigned)(L.d + 1);
-    L.csr_w[k] = L.bary[e];
+    L.csr_pw[k] = make_uint2(e / (unsigned)(L.d + 1), __float_as_uint(L.bary[e]));
     if (k == 0 || keys_sorted[k - 1] != key) L.vstart[key] = (unsigned)k;
     if (k == n_entries - 1 || keys_sorted[k + 1] != key) L.vend[key] = (unsigned)(k + 1);
 }
@@ -456,8 +455,7 @@ csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
                 if (same) {
                     const unsigned pos = b + (unsigned)__popcll(m & lt);
                     if (pos < n_entries_total) {
-                        L.csr_pix[pos] = (unsigned)(e / dp1);
-                        L.csr_w[pos] = wgt;
+                        L.csr_pw[pos] = make_uint2((unsigned)(e / dp1), __float_as_uint(wgt));   // one 8-byte store
                     }
                 }
                 if (lane == leader) my[k] = b + c;
@@ -660,15 +658,15 @@ size_t sort_temp_bytes(long long n_entries, int key_bits) {
 
 // norm values gathered into CSR order once the normaliser exists
 __global__ void __launch_bounds__(256)
-csr_norm_kernel(const unsigned* __restrict__ csr_pix, const float* __restrict__ norm, float* __restrict__ csr_nrm, long long n_entries,
+csr_norm_kernel(const uint2* __restrict__ csr_pw, const float* __restrict__ norm, float* __restrict__ csr_nrm, long long n_entries,
                 const int* __restrict__ counters) {
-    if (counters[1]) return;   // hash overflow (flagged): csr_pix is incomplete
+    if (counters[1]) return;   // hash overflow (flagged): the csr arrays are incomplete
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_entries) csr_nrm[k] = norm[csr_pix[k]];
+    if (k < n_entries) csr_nrm[k] = norm[csr_pw[k].x];
 }
 
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
-    csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pix, L.norm, L.csr_nrm, n_entries, L.counters);
+    csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pw, L.norm, L.csr_nrm, n_entries, L.counters);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -734,8 +732,9 @@ splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, flo
     auto load_entries = [&](unsigned tile, int slot) {
         unsigned k = k0 + tile * 64u + lane;
         k = k < k1 ? k : k1 - 1u;
-        w[slot] = L.csr_w[k];
-        if (MODE != 2) pix[slot] = L.csr_pix[k];
+        const uint2 pw = L.csr_pw[k];     // {point, weight} in one 8-byte load
+        w[slot] = __uint_as_float(pw.y);
+        pix[slot] = pw.x;
         if (MODE == 1) nrm[slot] = L.csr_nrm[k];
     };
     auto gather_rows = [&](int slot) {
@@ -986,7 +985,7 @@ constexpr int MF_LDS_BYTES = 48 * 1024;
 template <bool SEQ, int C, int DP1>   // DP1 = d+1 at compile time (wide offset / weight loads), 0 = runtime d
 __global__ void __launch_bounds__(256)
 mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float neg_w, ValueView unary, int negate,
-                 ValueView Q) {
+                 ValueView Q, int scale_out) {
     extern __shared__ __attribute__((aligned(16))) float tab[];
     if (L.counters[1]) return;   // uniform: hash overflow (flagged)
     constexpr int CP = (C + 3) / 4 * 4;
@@ -1058,18 +1057,22 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     const size_t qrow = Q.index((unsigned)p, 0, C, L.N);
 #pragma unroll
     for (int c = 0; c < C; c++) b[c] = b[c] / sum;
+    if (scale_out) {   // not the last iteration: hand the next splat its input Q * norm directly
+#pragma unroll
+        for (int c = 0; c < C; c++) b[c] = b[c] * nrm;
+    }
     store_row<C>(Q.base + qrow, b);
 }
 
 // returns false when C has no fused instantiation (the caller then runs the unfused kernels)
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
-                      const ValueView& Q, hipStream_t s) {
+                      const ValueView& Q, bool scale_out, hipStream_t s) {
     const float alpha = 1.0f / (1 + powf(2, (float)-L.d));
     const int bpf = (L.N + 255) / 256;
     const dim3 grid((unsigned)(bpf * L.n_frames)), block(256);
 #define RV_MF(SEQ, CC)                                                                                            \
-    if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q); \
-    else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q);       \
+    if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0); \
+    else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0); \
     return true
     switch (C) {
         case 2: RV_MF(true, 2);
@@ -1090,9 +1093,11 @@ bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg
 }
 
 // Q0 = expAndNormalize(-U) straight from the unary (densecrf.cpp:120), one thread per point
+// scale != nullptr: store fl(Q * scale[p]) instead of Q -- the input of the next splat
+// (DenseKernel::filter, pairwise.cpp:66), so the splat needs no per-entry normaliser
 template <int C>
 __global__ void __launch_bounds__(256)
-softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long n_points) {
+softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long n_points, const float* __restrict__ scale) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_points) return;
     const size_t urow = unary.index((unsigned)p, 0, C, N);
@@ -1109,12 +1114,18 @@ softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long 
     const size_t qrow = q.index((unsigned)p, 0, C, N);
 #pragma unroll
     for (int c = 0; c < C; c++) b[c] = b[c] / sum;
+    if (scale) {
+        const float sc = scale[p];
+#pragma unroll
+        for (int c = 0; c < C; c++) b[c] = b[c] * sc;
+    }
     store_row<C>(q.base + qrow, b);
 }
 
-bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {
+bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points,
+                          const float* scale, hipStream_t s) {
     const dim3 grid((unsigned)((n_points + 255) / 256)), block(256);
-#define RV_SU(CC) softmax_unary_kernel<CC><<<grid, block, 0, s>>>(unary, negate ? 1 : 0, N, q, n_points); return true
+#define RV_SU(CC) softmax_unary_kernel<CC><<<grid, block, 0, s>>>(unary, negate ? 1 : 0, N, q, n_points, scale); return true
     switch (C) {
         case 2: RV_SU(2); case 3: RV_SU(3); case 4: RV_SU(4); case 5: RV_SU(5); case 6: RV_SU(6); case 7: RV_SU(7);
         case 8: RV_SU(8); case 9: RV_SU(9); case 10: RV_SU(10); case 12: RV_SU(12); case 16: RV_SU(16); case 21: RV_SU(21);

@@ -28,9 +28,9 @@ struct LatticeDev {
     int* offsets;                // P x (d+1): slot, later vertex id
     float* bary;                 // P x (d+1)
     int *nb1, *nb2;              // (d+1) x m_bound blur neighbours (-1 = none)
-    unsigned* csr_pix;           // entries sorted by vertex, ascending point index inside a vertex
-    float* csr_w;                // barycentric weight of the entry
-    float* csr_nrm;              // norm[csr_pix] (available after the normaliser pass)
+    uint2* csr_pw;               // entries sorted by vertex, ascending point index inside a vertex:
+                                 // {point index, barycentric weight bits}
+    float* csr_nrm;              // norm[point] per entry (multi-kernel path only, built on demand)
     unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
     unsigned* vorder;            // vertex ids in splat launch order (grouped by frame mod n_groups, longest first)
     unsigned* gcount;            // vertices per group (8 counters)
@@ -98,9 +98,10 @@ void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const floa
                   long long n_points, hipStream_t s);
 // fused slice + Potts + softmax for a single pairwise kernel; false if C is not instantiated
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
-                      const ValueView& Q, hipStream_t s);
+                      const ValueView& Q, bool scale_out, hipStream_t s);
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);
-bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
+bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points,
+                          const float* scale, hipStream_t s);
 void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s);
 
 }  // namespace rvseg

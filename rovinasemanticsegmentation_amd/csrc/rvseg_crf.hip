@@ -12,12 +12,13 @@
 namespace rvseg {
 
 struct LatticeBufs {
-    DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pix, csr_w, csr_nrm, vstart, vend, norm;
+    DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pw, csr_nrm, vstart, vend, norm;
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount, block_hist, plist, pcount;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
     bool built = false;
+    bool has_csr_nrm = false;   // per-entry normaliser (multi-kernel inference only)
 };
 
 struct CrfState {
@@ -39,7 +40,7 @@ static CrfState* crf_state(Pipeline* im) {
 
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
-                     &b.csr_pix, &b.csr_w, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
+                     &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
                      &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount, &b.block_hist, &b.plist, &b.pcount};
     for (DevBuf* x : all) dev_free(*x);
 }
@@ -95,9 +96,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.bary, E * 4);
     RV_RES(b.nb1, m_bound * (d + 1) * 4);
     RV_RES(b.nb2, m_bound * (d + 1) * 4);
-    RV_RES(b.csr_pix, E * 4);
-    RV_RES(b.csr_w, E * 4);
-    RV_RES(b.csr_nrm, E * 4);
+    RV_RES(b.csr_pw, E * 8);
     RV_RES(b.vstart, m_bound * 4);
     RV_RES(b.vend, m_bound * 4);
     RV_RES(b.vorder, m_bound * 4);
@@ -127,7 +126,8 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.counters = b.counters.as<int>(); L.fstart = b.fstart.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
     L.offsets = b.offsets.as<int>(); L.bary = b.bary.as<float>();
     L.nb1 = b.nb1.as<int>(); L.nb2 = b.nb2.as<int>();
-    L.csr_pix = b.csr_pix.as<unsigned>(); L.csr_w = b.csr_w.as<float>(); L.csr_nrm = b.csr_nrm.as<float>();
+    L.csr_pw = b.csr_pw.as<uint2>(); L.csr_nrm = nullptr;
+    b.has_csr_nrm = false;
     L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.vorder = b.vorder.as<unsigned>(); L.norm = b.norm.as<float>();
     L.gcount = b.gcount.as<unsigned>();
     L.n_groups = n_frames >= 8 ? 8 : 1;
@@ -207,7 +207,6 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     launch_splat(L, none, 1, 2, cs->val_a.as<float>(), s);
     float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
     launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
-    launch_csr_norm(L, b.n_entries, s);
     tr("normaliser");
     RV_HIP(ctx, hipGetLastError());
     b.built = true;
@@ -243,10 +242,26 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
     for (int k = 0; k < n_kernels; k++) mb = std::max<long long>(mb, cs->lat[k].dev.m_bound);
     if ((st = values_reserve(ctx, cs, mb, C)) != RVSEG_OK) return st;
     float* tmp = cs->tmp.as<float>();
+    // Single Potts kernel with a fused instantiation: between iterations Q holds fl(Q * norm), the
+    // input of the next splat (pairwise.cpp:66), so the splat is a plain gather; only the last
+    // update stores the marginals themselves.
+    bool fused = n_kernels == 1 && iterations > 0;
     timer_mark(ctx, "softmax", s);
-    if (!launch_softmax_unary(unary, unary_is_energy, C, N, Q, n_points, s)) {
+    if (!launch_softmax_unary(unary, unary_is_energy, C, N, Q, n_points, fused ? cs->lat[0].dev.norm : nullptr, s)) {
+        fused = false;
         launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
         launch_softmax(tmp, C, N, Q, n_points, s);
+    }
+    if (!fused) {
+        // the general path scales by the normaliser inside the splat: per-entry copy of norm
+        for (int k = 0; k < n_kernels; k++) {
+            LatticeBufs& b = cs->lat[k];
+            if (b.has_csr_nrm) continue;
+            if ((st = dev_reserve(ctx, b.csr_nrm, (size_t)b.n_entries * 4)) != RVSEG_OK) return st;
+            b.dev.csr_nrm = b.csr_nrm.as<float>();
+            launch_csr_norm(b.dev, b.n_entries, s);
+            b.has_csr_nrm = true;
+        }
     }
     for (int it = 0; it < iterations; it++) {
         if (n_kernels == 1) {
@@ -254,11 +269,14 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             const LatticeBufs& b = cs->lat[0];
             const bool seq = C <= 2;
             timer_mark(ctx, "splat", s);
-            launch_splat(b.dev, Q, C, 1, cs->val_a.as<float>(), s);
+            launch_splat(b.dev, Q, C, fused ? 0 : 1, cs->val_a.as<float>(), s);
             timer_mark(ctx, "blur", s);
             float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
-            timer_mark(ctx, "mf_update", s);
-            if (launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, s)) continue;
+            if (fused) {
+                timer_mark(ctx, "mf_update", s);
+                launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, it + 1 < iterations, s);
+                continue;
+            }
             timer_mark(ctx, "softmax", s);
             launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
             timer_mark(ctx, "slice", s);
@@ -458,7 +476,11 @@ rvseg_status rvseg_lattice_neighbours(rvseg_ctx* ctx, int32_t* n1_out, int32_t* 
         if (n1_out) RV_HIP(ctx, hipMemcpy(n1_out + (size_t)j * M, lb.dev.nb1 + (size_t)j * lb.dev.m_bound, (size_t)M * 4, hipMemcpyDeviceToHost));
         if (n2_out) RV_HIP(ctx, hipMemcpy(n2_out + (size_t)j * M, lb.dev.nb2 + (size_t)j * lb.dev.m_bound, (size_t)M * 4, hipMemcpyDeviceToHost));
     }
-    if (csr_point) RV_HIP(ctx, hipMemcpy(csr_point, lb.dev.csr_pix, (size_t)lb.n_entries * 4, hipMemcpyDeviceToHost));
+    if (csr_point) {
+        std::vector<uint2> pw((size_t)lb.n_entries);
+        RV_HIP(ctx, hipMemcpy(pw.data(), lb.dev.csr_pw, (size_t)lb.n_entries * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < pw.size(); i++) csr_point[i] = pw[i].x;
+    }
     if (vstart) RV_HIP(ctx, hipMemcpy(vstart, lb.dev.vstart, (size_t)M * 4, hipMemcpyDeviceToHost));
     if (vend) RV_HIP(ctx, hipMemcpy(vend, lb.dev.vend, (size_t)M * 4, hipMemcpyDeviceToHost));
     return RVSEG_OK;
