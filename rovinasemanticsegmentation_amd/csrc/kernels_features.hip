@@ -85,8 +85,36 @@ __device__ __forceinline__ bool pair_fails(float z0, float z1) {
     return fabsf(z0 - z1) > thr || !finite_f(z0) || !finite_f(z1);
 }
 
+// PCL's depth-change map (integral_image_normal.hpp, computeFeature): a pixel is marked when it
+// belongs to a horizontal or vertical neighbour pair whose depths differ by more than
+// 0.02*(|z|+1)*2 or contain a non-finite value.  One thread per pixel, gather formulation.
+__global__ void __launch_bounds__(256)
+change_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __restrict__ change_all, int n_frames) {
+    const size_t npix = (size_t)g.W * g.H;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= npix * (size_t)n_frames) return;
+    const int frame = (int)(gid / npix);
+    const int pix = (int)(gid - (size_t)frame * npix);
+    const int W = g.W, H = g.H;
+    const int r = pix / W, c = pix - r * W;
+    const float4* cloud = cloud_all + (size_t)frame * npix;
+    const float z = cloud[pix].z;
+    bool change = false;
+    if (r <= H - 2 && c <= W - 2)
+        change = pair_fails(z, cloud_z(cloud, W, r, c + 1)) || pair_fails(z, cloud_z(cloud, W, r + 1, c));
+    if (!change && c >= 1 && r <= H - 2) change = pair_fails(cloud_z(cloud, W, r, c - 1), z);
+    if (!change && r >= 1 && c <= W - 2) change = pair_fails(cloud_z(cloud, W, r - 1, c), z);
+    change_all[gid] = change ? 1 : 0;
+}
+
+// value of the lane below in the wave (lane l takes lane l-1's); lane 0 takes `edge`
+__device__ __forceinline__ float wave_shr1(float v, float edge) {
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+
 __global__ void __launch_bounds__(64)
-window_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __restrict__ rect_all) {
+window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* __restrict__ rect_all) {
     __shared__ float dist[DM_CH * DM_CW];
     __shared__ int any_zero;
     const int W = g.W, H = g.H;
@@ -96,7 +124,7 @@ window_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __
     const int tile = blockIdx.x - frame * tiles_x * tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * DM_TW - DM_APRON, y0 = ty * DM_TH - DM_APRON;
-    const float4* cloud = cloud_all + (size_t)frame * W * H;
+    const uint8_t* change = change_all + (size_t)frame * W * H;
     uint8_t* rect = rect_all + (size_t)frame * W * H;
     const int lane = threadIdx.x;
     const float BIG = (float)(W + H);
@@ -108,62 +136,71 @@ window_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __
         const int lr = idx / DM_CW, lc = idx - lr * DM_CW;
         const int r = y0 + lr, c = x0 + lc;
         float v = BIG;
-        if (r >= 0 && r < H && c >= 0 && c < W) {
-            const float z = cloud_z(cloud, W, r, c);
-            bool change = false;
-            if (r <= H - 2 && c <= W - 2)
-                change = pair_fails(z, cloud_z(cloud, W, r, c + 1)) || pair_fails(z, cloud_z(cloud, W, r + 1, c));
-            if (!change && c >= 1 && r <= H - 2) change = pair_fails(cloud_z(cloud, W, r, c - 1), z);
-            if (!change && r >= 1 && c <= W - 2) change = pair_fails(cloud_z(cloud, W, r - 1, c), z);
-            if (change) { v = 0.0f; my_zero = 1; }
-        }
+        if (r >= 0 && r < H && c >= 0 && c < W && change[(size_t)r * W + c]) { v = 0.0f; my_zero = 1; }
         dist[idx] = v;
     }
     if (my_zero) any_zero = 1;
     __syncthreads();
 
     if (any_zero) {
-        // first pass: rows 1..H-1, columns 1..W-1 of the image, raster order
+        // Lane l owns one row of the tile and walks it left to right, two columns behind the lane
+        // above (anti-diagonal t = 2*row + col).  The three upper neighbours are the last three
+        // results of lane l-1 and arrive by a one-lane wave shift (DPP, no LDS round trip); the
+        // left neighbour is the lane's own previous result.  Only the initial value of a cell is
+        // read from LDS (prefetched one step ahead) and its final value written back.
         const int n_steps = 2 * (DM_CH - 1) + DM_CW;
-        for (int t = 0; t < n_steps; t++) {
-            const int lr = lane, lc = t - 2 * lane;
-            if (lr < DM_CH && lc >= 0 && lc < DM_CW) {
-                const int r = y0 + lr, c = x0 + lc;
-                if (r >= 1 && r < H && c >= 1 && c < W) {
-                    const float* cur = dist + lr * DM_CW;
-                    const bool has_prev = lr >= 1;
-                    const float* prev = cur - DM_CW;
-                    const float upLeft = (has_prev && lc >= 1 ? prev[lc - 1] : BIG) + 1.4f;
-                    const float up = (has_prev ? prev[lc] : BIG) + 1.0f;
-                    const float upRight = (has_prev && lc + 1 < DM_CW && c + 1 < W ? prev[lc + 1] : BIG) + 1.4f;
-                    const float left = (lc >= 1 ? cur[lc - 1] : BIG) + 1.0f;
-                    const float center = cur[lc];
-                    const float mn = fminf(fminf(upLeft, up), fminf(left, upRight));
-                    if (mn < center) dist[lr * DM_CW + lc] = mn;
+        const bool row_ok = lane < DM_CH;
+        // ---- first pass: rows 1..H-1, columns 1..W-1 of the image, raster order
+        {
+            const int lr = lane;
+            const int r = y0 + lr;
+            float o1 = BIG, o2 = BIG, o3 = BIG;          // this lane's results at steps t-1, t-2, t-3
+            int lc = -2 * lane;
+            float center_next = (row_ok && lc >= 0 && lc < DM_CW) ? dist[lr * DM_CW + lc] : BIG;
+            for (int t = 0; t < n_steps; t++, lc++) {
+                const float center = center_next;
+                const int lcn = lc + 1;
+                center_next = (row_ok && lcn >= 0 && lcn < DM_CW) ? dist[lr * DM_CW + lcn] : BIG;
+                // results of the lane above: step t-1 -> column lc+1, t-2 -> lc, t-3 -> lc-1
+                float upRight = wave_shr1(o1, BIG), up = wave_shr1(o2, BIG), upLeft = wave_shr1(o3, BIG);
+                const int c = x0 + lc;
+                if (c + 1 >= W) upRight = BIG;           // prev[W] belongs to the next image row
+                const bool in_tile = row_ok && lc >= 0 && lc < DM_CW;
+                float out = in_tile ? center : BIG;
+                if (in_tile && r >= 1 && r < H && c >= 1 && c < W) {
+                    const float mn = fminf(fminf(upLeft + 1.4f, up + 1.0f), fminf(o1 + 1.0f, upRight + 1.4f));
+                    if (mn < center) { out = mn; dist[lr * DM_CW + lc] = mn; }
                 }
+                o3 = o2; o2 = o1; o1 = out;
             }
-            __syncthreads();
         }
-        // second pass: rows H-2..0, columns W-2..0, reverse raster order
-        for (int t = 0; t < n_steps; t++) {
-            const int lr = DM_CH - 1 - lane, lc = DM_CW - 1 - (t - 2 * lane);
-            if (lr >= 0 && lc >= 0 && lc < DM_CW && (t - 2 * lane) >= 0) {
-                const int r = y0 + lr, c = x0 + lc;
-                if (r >= 0 && r <= H - 2 && c >= 0 && c <= W - 2) {
-                    const float* cur = dist + lr * DM_CW;
-                    const bool has_next = lr + 1 < DM_CH;
-                    const float* next = cur + DM_CW;
-                    const float lowerLeft = (has_next && lc >= 1 && c >= 1 ? next[lc - 1] : BIG) + 1.4f;
-                    const float lower = (has_next ? next[lc] : BIG) + 1.0f;
-                    const float lowerRight = (has_next && lc + 1 < DM_CW ? next[lc + 1] : BIG) + 1.4f;
-                    const float right = (lc + 1 < DM_CW ? cur[lc + 1] : BIG) + 1.0f;
-                    const float center = cur[lc];
-                    const float mn = fminf(fminf(lowerLeft, lower), fminf(right, lowerRight));
-                    if (mn < center) dist[lr * DM_CW + lc] = mn;
+        __syncthreads();
+        // ---- second pass: rows H-2..0, columns W-2..0, reverse raster order (lane l <-> row CH-1-l)
+        {
+            const int lr = DM_CH - 1 - lane;
+            const int r = y0 + lr;
+            float o1 = BIG, o2 = BIG, o3 = BIG;
+            int cp = -2 * lane;                          // mirrored column index
+            float center_next = (row_ok && cp >= 0 && cp < DM_CW) ? dist[lr * DM_CW + (DM_CW - 1 - cp)] : BIG;
+            for (int t = 0; t < n_steps; t++, cp++) {
+                const float center = center_next;
+                const int cpn = cp + 1;
+                center_next = (row_ok && cpn >= 0 && cpn < DM_CW) ? dist[lr * DM_CW + (DM_CW - 1 - cpn)] : BIG;
+                const int lc = DM_CW - 1 - cp;
+                // lane l-1 is the row below: its step t-1 is column lc-1, t-2 -> lc, t-3 -> lc+1
+                float lowerLeft = wave_shr1(o1, BIG), lower = wave_shr1(o2, BIG), lowerRight = wave_shr1(o3, BIG);
+                const int c = x0 + lc;
+                if (c < 1) lowerLeft = BIG;              // next[-1] belongs to the previous image row
+                const bool in_tile = row_ok && cp >= 0 && cp < DM_CW;
+                float out = in_tile ? center : BIG;
+                if (in_tile && r >= 0 && r <= H - 2 && c >= 0 && c <= W - 2) {
+                    const float mn = fminf(fminf(lowerLeft + 1.4f, lower + 1.0f), fminf(o1 + 1.0f, lowerRight + 1.4f));
+                    if (mn < center) { out = mn; dist[lr * DM_CW + lc] = mn; }
                 }
+                o3 = o2; o2 = o1; o1 = out;
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
     // window size per pixel of the tile: 0 <=> NaN normal (smoothing <= 2), else int(smoothing)
     for (int idx = lane; idx < DM_TH * DM_TW; idx += 64) {
@@ -340,9 +377,11 @@ void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb,
         g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, n);
 }
 
-void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_rect, int n, hipStream_t s) {
+void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_change, uint8_t* d_rect, int n, hipStream_t s) {
+    const size_t total = (size_t)g.W * g.H * n;
+    change_map_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, d_cloud, d_change, n);
     const int tiles = ((g.W + DM_TW - 1) / DM_TW) * ((g.H + DM_TH - 1) / DM_TH);
-    window_map_kernel<<<dim3((unsigned)(tiles * n)), dim3(64), 0, s>>>(g, d_cloud, d_rect);
+    window_map_kernel<<<dim3((unsigned)(tiles * n)), dim3(64), 0, s>>>(g, d_change, d_rect);
 }
 
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,

@@ -12,7 +12,7 @@ struct Pipeline {
     DevBuf resize_rows;
     UpsampleTables up;
     // per-chunk device buffers (grow-only, sized for up to max_batch frames)
-    DevBuf calibA, lab, cloud, rect, nfeat, low, post, marg, labels, in_rgb, in_depth, dump, valid;
+    DevBuf calibA, lab, cloud, change, rect, nfeat, low, post, marg, labels, in_rgb, in_depth, dump, valid;
     float* h_calibA = nullptr;  // pinned staging for the per-frame A = R*Kinv, t
     size_t h_calibA_bytes = 0;
     CrfState* crf = nullptr;

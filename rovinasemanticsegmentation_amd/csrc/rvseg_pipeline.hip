@@ -106,7 +106,7 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
 static void pipeline_free(Pipeline* im) {
     DevBuf* all[] = {&im->resize_rows, &im->up.xofs, &im->up.ax0, &im->up.ax1, &im->up.yofs, &im->up.ay0, &im->up.ay1,
                      &im->calibA, &im->lab, &im->cloud, &im->rect, &im->nfeat, &im->low, &im->post, &im->marg,
-                     &im->labels, &im->in_rgb, &im->in_depth, &im->dump, &im->valid};
+                     &im->labels, &im->in_rgb, &im->in_depth, &im->dump, &im->valid, &im->change};
     for (DevBuf* b : all) dev_free(*b);
     if (im->h_calibA) (void)hipHostFree(im->h_calibA);
     crf_state_free(im);
@@ -166,6 +166,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     if (need_cloud && (st = dev_reserve(ctx, im->cloud, npix * 16 * n)) != RVSEG_OK) return st;
     if (p.feature_normal) {
         if ((st = dev_reserve(ctx, im->rect, npix * n)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, im->change, npix * n)) != RVSEG_OK) return st;
         if ((st = dev_reserve(ctx, im->nfeat, (size_t)g.lw * g.lh * 4 * n)) != RVSEG_OK) return st;
     }
     if ((st = dev_reserve(ctx, im->low, (size_t)g.lw * g.lh * f.sum_classes * 4 * n)) != RVSEG_OK) return st;
@@ -179,7 +180,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
                 need_cloud ? im->cloud.as<float4>() : nullptr, n, s);
     if (p.feature_normal) {
         timer_mark(ctx, "window_map", s);
-        launch_window_map(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), n, s);
+        launch_window_map(g, im->cloud.as<float4>(), im->change.as<uint8_t>(), im->rect.as<uint8_t>(), n, s);
         timer_mark(ctx, "normal_feature", s);
         launch_normal_feature(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), im->nfeat.as<float>(), n, s);
     }
@@ -303,6 +304,7 @@ rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const ui
     if ((st = dev_reserve(ctx, im->lab, npix * 4)) != RVSEG_OK) return st;
     if ((st = dev_reserve(ctx, im->cloud, npix * 16)) != RVSEG_OK) return st;
     if ((st = dev_reserve(ctx, im->rect, npix)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, im->change, npix)) != RVSEG_OK) return st;
     if ((st = dev_reserve(ctx, im->nfeat, (size_t)P * 4)) != RVSEG_OK) return st;
     if ((st = dev_reserve(ctx, im->dump, (size_t)P * g.D * 4)) != RVSEG_OK) return st;
     if ((st = dev_reserve(ctx, im->valid, (size_t)P)) != RVSEG_OK) return st;
@@ -312,7 +314,7 @@ rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const ui
     launch_prep(g, ctx->lab, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
                 im->lab.as<uint32_t>(), im->cloud.as<float4>(), 1, s);
     if (p.feature_normal) {
-        launch_window_map(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), 1, s);
+        launch_window_map(g, im->cloud.as<float4>(), im->change.as<uint8_t>(), im->rect.as<uint8_t>(), 1, s);
         launch_normal_feature(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), im->nfeat.as<float>(), 1, s);
     }
     // the dump variant never touches the forest; a context without a model can still extract
