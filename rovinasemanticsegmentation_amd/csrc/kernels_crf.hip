@@ -439,6 +439,12 @@ csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
         int lv = valid ? id - f0 : -1;
         if (lv >= Mf) lv = Mf - 1;                   // overflow case (flagged elsewhere): stay in bounds
         if (valid && lv < 0) lv = 0;
+        if (!SCATTER) {
+            // counting needs no order: LDS atomics (same-address lanes serialise in hardware, still an
+            // order of magnitude cheaper than ranking the chunk with ballots)
+            if (valid) atomicAdd(&my[lv], 1u);
+            continue;
+        }
         bool pending = valid;
         // distinct vertex ids of a chunk touch distinct counters, so the loop needs no ordering
         // inside a chunk; one fence per chunk orders the counters between chunks
