@@ -44,6 +44,27 @@ STAGE_BYTES_PER_PX = {
 }
 PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.md 8d
 
+# stage name -> kernel whose PMC counters (profiles/*_pmc_batch64.json, collected with separate
+# rocprofv3 --pmc passes of this very command) give the HBM traffic per launch
+STAGE_KERNEL = {"splat": "rvseg::splat_gather_kernel<0, 9, false>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
+                "rf_frames": "rvseg::rf_frames_kernel<false>"}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed PMC summary: FETCH_SIZE and
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane loads
+    (MI355X_MICROARCH.md, HBM section), which is what these kernels issue, so it is doubled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_batch64.json")))
+    if not files or stage not in STAGE_KERNEL:
+        return None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    r = d.get(STAGE_KERNEL[stage])
+    if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
+        return None
+    return (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -172,7 +193,8 @@ def main():
             avg_ms = stages[dom] / k
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": pmc_traffic(dom) if n == FRAMES_PER_STEP else None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": k,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         out = {
