@@ -59,3 +59,11 @@ def test_create_rejects_bad_params_before_touching_the_device():
     for kw in ({"stride": 0}, {"width": 2}, {"depth_min": 0.1}, {"max_batch": 0}, {"label_mode": 9}):
         p = capi.default_params(**kw)
         assert capi.lib().rvseg_create(C.byref(p), C.byref(h)) == capi.ERR_INVALID_ARG, kw
+
+
+def test_cpp_facade_header_compiles():
+    """include/rvseg_segmenter.hpp (the C++ mirror of `class Segmenter`) is plain C++17 over the C ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "segmenter_facade_test.cpp")])

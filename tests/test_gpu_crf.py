@@ -133,3 +133,41 @@ def test_frames_with_crf_bit_exact(gpu_ctx_factory, oracle):
     # marginals are distributions
     m = out["marginals"][0][: 640 * 480 * 8].reshape(-1, 8)
     assert np.allclose(m.sum(1), 1, atol=1e-5)
+
+
+def test_range_major_splat_is_bit_exact_too(gpu_ctx_factory, oracle):
+    """RVSEG_SPLAT_RANGE=1 orders the entries (range, vertex, point) and carries the running sums
+    from range to range; the additions per vertex stay in point order, so nothing may change."""
+    blob = synthetic.make_forest_bytes(seed=22, n_trees=3, leaves_per_tree=256, max_depth=12)
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(1, holes=True, start=5)
+    calib = synthetic.make_calib()
+    os.environ["RVSEG_SPLAT_RANGE"] = "1"
+    try:
+        ctx = gpu_ctx_factory(use_dense_crf=1, dcrf_iterations=2, label_mode=3)
+        ctx.forest_load(blob)
+        out = ctx.segment_frames(rgb, depth, calib)
+    finally:
+        del os.environ["RVSEG_SPLAT_RANGE"]
+    p = oracle.default_params(dcrf_iterations=2)
+    post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[0], depth[0], calib, label_mode=3)
+    assert np.array_equal(out["marginals"][0], marg)
+    assert np.array_equal(out["labels"][0].ravel(), lab)
+
+
+def test_config5_shape_dual_layer_10_iterations(gpu_ctx_factory, oracle):
+    """BASELINE configs[4] at one frame: 1280x960, dual-layer forest, 10 CRF iterations."""
+    W, H = 1280, 960
+    blob = synthetic.make_forest_bytes(seed=23, n_trees=4, leaves_per_tree=512, max_depth=14)
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(1, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(width=W, height=H, use_dense_crf=1, dcrf_iterations=10, label_mode=1, max_batch=1)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    p = oracle.default_params(width=W, height=H, dcrf_iterations=10)
+    post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[0], depth[0], calib, label_mode=1, unknown=[7, 8])
+    assert np.array_equal(out["posteriors"][0], post)
+    assert np.abs(out["marginals"][0] - marg).max() <= TOL
+    assert np.array_equal(out["marginals"][0], marg)
+    assert np.array_equal(out["labels"][0].ravel(), lab)

@@ -115,3 +115,25 @@ def test_stride_must_divide_image(gpu_ctx_factory):
     ctx = gpu_ctx_factory(width=101, height=52, patch_size=9, patch_size_reduce=3, feature_color_patch=0)
     with pytest.raises(rv.capi.RvsegError):
         ctx.extract_features(np.zeros((52, 101, 3), np.uint8), np.zeros((52, 101), np.uint16), synthetic.make_calib(101, 52))
+
+
+def test_frame_without_any_valid_depth(gpu_ctx_factory, oracle):
+    """No sample point passes the mask: the low-res image keeps the fill value everywhere and the
+    labels follow the rule for it (eval rule: -1 with fill -1000; node rule: unknown with fill 0)."""
+    blob = synthetic.make_forest_bytes(seed=4, n_trees=2, leaves_per_tree=32, max_depth=6)
+    rgb, _ = synthetic.make_batch(1)
+    depth = np.zeros((1, 480, 640), np.uint16)
+    calib = synthetic.make_calib()
+    ctx = gpu_ctx_factory(multi_layer=0, fill_value=-1000.0, label_mode=0)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    assert (out["posteriors"] == -1000.0).all() and (out["labels"] == -1).all()
+    feat, xv, yv = ctx.extract_features(rgb[0], depth[0], calib)
+    assert feat.shape[0] == 0
+    ctx2 = gpu_ctx_factory(multi_layer=1, fill_value=0.0, label_mode=2)
+    ctx2.forest_load(blob)
+    out = ctx2.segment_frames(rgb, depth, calib)
+    assert (out["posteriors"] == 0).all()
+    assert (out["labels"][0, 0] == 7).all() and (out["labels"][0, 1] == 8).all()
+    # zero frames is a no-op
+    ctx2.L.rvseg_segment_frames(ctx2.h, 0, None, None, None, None, None, None)
