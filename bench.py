@@ -104,12 +104,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switches for a one-GPU box: RVSEG_BENCH_BACKEND=gloo RVSEG_BENCH_SAME_DEVICE=1 runs the
+    # multi-rank code path with all ranks on cuda:0 (never used by the driver)
+    backend = os.environ.get("RVSEG_BENCH_BACKEND", "nccl")
+    same_device = os.environ.get("RVSEG_BENCH_SAME_DEVICE", "0") == "1"
+    dev_index = 0 if (same_device or world == 1) else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     import rovinasemanticsegmentation_amd as rv
@@ -156,7 +164,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
