@@ -17,6 +17,7 @@
 //     index.  To stay bit-exact the splat is a GATHER: entries are stably sorted by vertex and each
 //     (vertex, class) chain adds its contributions in ascending point order.  No float atomics.
 #include <cstring>
+#include <type_traits>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -624,7 +625,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
 // the same XCD and shares its L2 (speed only, never correctness); inside a group longest list
 // first (LPT: the serial chains of the heaviest vertices start at t = 0).
 __global__ void __launch_bounds__(256)
-vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids) {
+vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids, int frame_major) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.m_bound) return;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
@@ -634,6 +635,10 @@ vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict
         const unsigned frame = (unsigned)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
         const unsigned g = frame % (unsigned)L.n_groups;
         k = (g << 28) | (0x0FFFFFFFu - (len < 0x0FFFFFFFu ? len : 0x0FFFFFFFu));
+        if (frame_major) {
+            const unsigned fr = frame / (unsigned)L.n_groups, l16 = len >> 4;
+            k = (g << 28) | ((fr < 255u ? fr : 255u) << 20) | (0xFFFFFu - (l16 < 0xFFFFFu ? l16 : 0xFFFFFu));
+        }
         atomicAdd(L.gcount + g, 1u);
     }
     key[v] = k;
@@ -642,7 +647,8 @@ vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict
 
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
     (void)hipMemsetAsync(L.gcount, 0, 8 * sizeof(unsigned), s);
-    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in);
+    static const int frame_major = getenv("RVSEG_SPLAT_FRAME_MAJOR") ? atoi(getenv("RVSEG_SPLAT_FRAME_MAJOR")) : 0;
+    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, frame_major);
     size_t temp = sb.temp_bytes;
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
 }
@@ -801,6 +807,159 @@ splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, flo
   }
 }
 
+
+// Grouped form of the same sum (the default).  PMC on the one-wave-per-vertex kernel above showed it
+// issue bound: of ~150 instructions per 64-entry tile, 64 adds + 16 LDS reads run with only C of 64
+// lanes busy.  Here a block owns G = 64 / CC vertices of similar list length (neighbours in
+// `vorder`): wave i < G forms the products of vertex i's tile t exactly as above, and ONE extra
+// wave adds them for all G vertices at once -- lane (i, c) walks vertex i's class-c products in
+// list order -- so the sequential phase costs 64 adds per G tiles.  Products are double buffered:
+// the adder works on tile t while the producers write tile t + 1; one barrier per tile.
+template <int CC> struct SplatGroup { static constexpr int G = 64 / CC > 8 ? 8 : 64 / CC; };
+// A vertex's chain advances one tile per barrier, so the loads of a tile have to be in flight for
+// many tiles: {point, weight} pairs are fetched SPLAT_RE - 1 tiles ahead and the Q rows they point at
+// SPLAT_RR - 1 tiles ahead (the one-wave kernel above keeps 3 / 2 and stalls a memory round trip per tile).
+constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is written out for RE == 16
+
+template <int MODE, int CC, bool FULL>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
+__global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64)
+splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
+    constexpr int G = SplatGroup<CC>::G;
+    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];  // 16-B aligned rows, 4-bank skew
+    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // block b -> group b % n_groups (= the XCD it lands on when n_groups == 8), rank b / n_groups inside it
+    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j0 = blockIdx.x / (unsigned)L.n_groups;
+    const unsigned jstep = gridDim.x / (unsigned)L.n_groups;
+    const unsigned n_vert = L.gcount[g];
+    unsigned gstart = 0;
+    for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
+    const unsigned n_items = (n_vert + G - 1) / G;
+    const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
+    for (unsigned j = j0; j < n_items; j += jstep) {
+        // every wave reads the group's G list ranges itself (uniform): no broadcast step
+        unsigned n_steps = 0, my_k0 = 0, my_k1 = 0;
+        for (int i = 0; i < G; i++) {
+            const unsigned idx = j * G + i;
+            if (idx < n_vert) {
+                const unsigned v = L.vorder[gstart + idx];
+                const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+                const unsigned nt = (k1 - k0 + 63u) / 64u;
+                n_steps = nt > n_steps ? nt : n_steps;
+                if (i == wave) { my_k0 = k0; my_k1 = k1; }
+            }
+        }
+        // the launch lasts as long as its longest chains: their waves win issue arbitration on a shared SIMD
+        if (n_steps > 512u) __builtin_amdgcn_s_setprio(3);
+        else if (n_steps > 128u) __builtin_amdgcn_s_setprio(2);
+        else if (n_steps > 32u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        if (wave < G) {
+            // ---- producer of vertex `wave`: barriers 0 .. n_steps - 1 close its tiles, one more ends the item
+            const bool has = my_k1 > my_k0;
+            const unsigned kc0 = has ? my_k0 : 0u, kc1 = has ? my_k1 : 1u;   // clamp range of the loads (entry 0 exists)
+            const unsigned n_tiles = has ? (my_k1 - my_k0 + 63u) / 64u : 0u;
+            float x[SPLAT_RR][CC];
+            float w[SPLAT_RE], nrm[SPLAT_RE];
+            unsigned pix[SPLAT_RE];
+#pragma unroll
+            for (int r = 0; r < SPLAT_RE; r++) { w[r] = 0.f; nrm[r] = 1.f; pix[r] = 0u; }
+            // loads are unconditional (indices clamped into the list): no divergent branch, counted waits
+            auto load_entries = [&](unsigned tile, int slot) {
+                unsigned k = kc0 + tile * 64u + lane;
+                k = k < kc1 ? k : kc1 - 1u;
+                const uint2 pw = L.csr_pw[k];
+                w[slot] = __uint_as_float(pw.y);
+                pix[slot] = pw.x;
+                if (MODE == 1) nrm[slot] = L.csr_nrm[k];
+            };
+            auto gather_rows = [&](int eslot, int rslot) {
+                if (MODE == 2) return;
+                // one frame-contiguous [point][C] matrix (the single-layer case): no division by N
+                const size_t row = contig ? (size_t)pix[eslot] * (unsigned)C + (unsigned)c0 : src.index(pix[eslot], c0, C, L.N);
+                if (FULL) {
+                    load_row<CC>(src.base + row, x[rslot]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CC; c++) x[rslot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < SPLAT_RE - 1; i++) load_entries((unsigned)i, i);
+#pragma unroll
+            for (int i = 0; i < SPLAT_RR - 1; i++) gather_rows(i, i);
+            // one tile: products -> LDS, refill the two rings, barrier.  `S` is a compile-time ring position
+            // (the rings live in registers); a `false` return leaves the loop, so no stage is reachable
+            // past a skipped one and the compiler keeps counted vmcnt waits.
+            auto stage = [&](unsigned t, auto S) -> bool {
+                constexpr int s = decltype(S)::value;
+                if (t >= n_steps) return false;
+                const unsigned base = my_k0 + t * 64u;
+                const unsigned n_valid = t < n_tiles ? (my_k1 - base < 64u ? my_k1 - base : 64u) : 0u;
+                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
+                float (*pb)[68] = prod[t & 1u][wave];
+#pragma unroll
+                for (int c = 0; c < CC; c++) {
+                    float xin = MODE == 2 ? 1.0f : x[s % SPLAT_RR][c];
+                    if (MODE == 1) xin = xin * nrm[s];
+                    const float pr = wl * xin;
+                    pb[c][lane] = (unsigned)lane < n_valid ? pr : 0.0f;   // +0 past the list: identity of the sum
+                }
+                load_entries(t + SPLAT_RE - 1, (s + SPLAT_RE - 1) % SPLAT_RE);
+                gather_rows((s + SPLAT_RR - 1) % SPLAT_RE, (s + SPLAT_RR - 1) % SPLAT_RR);
+                __syncthreads();
+                return true;
+            };
+#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
+            for (unsigned t0 = 0;; t0 += SPLAT_RE) {
+                RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
+                RV_ST(8) RV_ST(9) RV_ST(10) RV_ST(11) RV_ST(12) RV_ST(13) RV_ST(14) RV_ST(15)
+            }
+#undef RV_ST
+            __syncthreads();
+        } else {
+            // ---- adder: lane (i, c) owns the chain of vertex i, class c
+            const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
+            float acc = 0.0f;
+            __syncthreads();
+            for (unsigned t = 0; t < n_steps; t++) {
+                const float* pr = prod[t & 1u][gi][c];
+                float4 q[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+                __syncthreads();
+            }
+            const unsigned idx = j * G + gi;
+            if (lane < G * CC && idx < n_vert && c < n_store) {
+                const unsigned v = L.vorder[gstart + idx];
+                values[(size_t)v * C + c0 + c] = acc;
+            }
+        }
+    }
+}
+
+template <int MODE, int CC>
+static void splat_group_launch(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
+    constexpr int G = SplatGroup<CC>::G;
+    const unsigned per_group = (L.splat_grid / (unsigned)L.n_groups + G - 1) / G;
+    const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
+    if (n == CC) splat_group_kernel<MODE, CC, true><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else splat_group_kernel<MODE, CC, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+}
+
+template <int MODE>
+static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
+    if (n == 1) splat_group_launch<MODE, 1>(L, src, C, c0, n, values, s);
+    else if (n == 2) splat_group_launch<MODE, 2>(L, src, C, c0, n, values, s);
+    else if (n <= 4) splat_group_launch<MODE, 4>(L, src, C, c0, n, values, s);
+    else if (n <= 8) splat_group_launch<MODE, 8>(L, src, C, c0, n, values, s);
+    else if (n == 9) splat_group_launch<MODE, 9>(L, src, C, c0, n, values, s);
+    else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
+}
+
 template <int MODE, bool RANGE>
 static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, int range, hipStream_t s) {
     const dim3 grid(RANGE ? L.range_grid : L.splat_grid), block(64);
@@ -829,14 +988,27 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         }
         return;
     }
+    static const bool wave_per_vertex = getenv("RVSEG_SPLAT_WAVE") && atoi(getenv("RVSEG_SPLAT_WAVE")) != 0;
+    if (wave_per_vertex) {   // the earlier kernel, kept for A/B timing
+        if (mode == 2) {
+            splat_gather_kernel<2, 1, false><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, 0);
+            return;
+        }
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            const int n = C - c0 < 16 ? C - c0 : 16;
+            if (mode == 0) splat_pass<0, false>(L, src, C, c0, n, values, 0, s);
+            else splat_pass<1, false>(L, src, C, c0, n, values, 0, s);
+        }
+        return;
+    }
     if (mode == 2) {
-        splat_gather_kernel<2, 1, false><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, 0);
+        splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;
     }
     for (int c0 = 0; c0 < C; c0 += 16) {
         const int n = C - c0 < 16 ? C - c0 : 16;
-        if (mode == 0) splat_pass<0, false>(L, src, C, c0, n, values, 0, s);
-        else splat_pass<1, false>(L, src, C, c0, n, values, 0, s);
+        if (mode == 0) splat_group_pass<0>(L, src, C, c0, n, values, s);
+        else splat_group_pass<1>(L, src, C, c0, n, values, s);
     }
 }
 
