@@ -478,6 +478,80 @@ csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     }
 }
 
+// Scatter pass with one lane per POINT (the generic pass above has one lane per entry and ranks ~10
+// distinct vertices per 64 entries; PMC: 438 vector instructions per 64 entries).  A chunk is 64
+// consecutive points x DP1 entries.  For every distinct vertex k of the chunk the lanes that hold k
+// -- in any of their DP1 slots, at most one per lane since a point's vertices are distinct -- are
+// found with DP1 ballots; their union, masked to the lower lanes, is the rank of a point among the
+// chunk's entries of k, i.e. ascending point order again.  Neighbouring points share their simplex,
+// so a chunk has ~12-20 distinct vertices for 448 entries.
+template <int DP1>
+__global__ void __launch_bounds__(256)
+csr_scatter_kernel(LatticeDev L, const unsigned* __restrict__ bh, int wbpf, int mcap) {
+    extern __shared__ unsigned cs_cnt[];   // [4 waves][mcap]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long gwb = (long long)blockIdx.x * 4 + wave;
+    const int frame = (int)(gwb / wbpf);
+    if (frame >= L.n_frames) return;       // whole wave; no block-wide barrier below
+    const int wb = (int)(gwb - (long long)frame * wbpf);
+    // (clamps only matter after a flagged hash overflow; they keep every access in bounds)
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const unsigned n_entries_total = (unsigned)((long long)L.n_frames * L.N * DP1);
+    unsigned* my = cs_cnt + (size_t)wave * mcap;
+    const unsigned* row = bh + (size_t)wbpf * f0 + (size_t)wb * Mf;
+    for (int lv = lane; lv < Mf; lv += 64) my[lv] = row[lv];
+    if (Mf == 0 && lane == 0) my[0] = 0xFFFFFFFFu;   // no vertices (overflow only): positions fail the bound check
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int p0 = wb * CS_PIX;
+    const int p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int pc = p0; pc < p1; pc += 64) {
+        const int p = pc + lane;
+        const bool valid = p < p1;
+        const size_t gp = (size_t)frame * L.N + (valid ? p : p1 - 1);
+        int lv[DP1];
+        float w[DP1];
+        load_row<DP1>(L.offsets + gp * DP1, lv);
+        load_row<DP1>(L.bary + gp * DP1, w);
+#pragma unroll
+        for (int j = 0; j < DP1; j++) {
+            lv[j] -= f0;
+            lv[j] = lv[j] < Mf ? lv[j] : Mf - 1;   // overflow case (flagged elsewhere): stay in bounds
+            lv[j] = lv[j] < 0 ? 0 : lv[j];
+        }
+        unsigned pend = valid ? (1u << DP1) - 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < DP1; j++) {
+            for (;;) {
+                const unsigned long long todo = __ballot((pend >> j) & 1u);
+                if (!todo) break;
+                const int leader = __ffsll((long long)todo) - 1;
+                const int k = __builtin_amdgcn_readlane(lv[j], leader);
+                // slots below j are already empty for every lane; a vertex handled in an earlier pass
+                // was removed from all slots then, so it cannot come up again in this chunk
+                unsigned long long all = 0ull;
+                float wsel = 0.0f;
+                bool hit = false;
+#pragma unroll
+                for (int jj = j; jj < DP1; jj++) {
+                    const bool same = ((pend >> jj) & 1u) && lv[jj] == k;
+                    all |= __ballot(same);
+                    if (same) { wsel = w[jj]; hit = true; pend &= ~(1u << jj); }
+                }
+                const unsigned b = my[k];
+                if (hit) {
+                    const unsigned pos = b + (unsigned)__popcll(all & lt);
+                    if (pos < n_entries_total) L.csr_pw[pos] = make_uint2((unsigned)gp, __float_as_uint(wsel));
+                }
+                if (lane == leader) my[k] = b + (unsigned)__popcll(all);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
+
 // per frame: bh[wb][lv] (counts) -> absolute base of (wave-block, vertex) in the csr arrays;
 // vstart / vend per vertex.  1024 threads = 16 wave-block segments x 64 vertices.
 __global__ void __launch_bounds__(1024)
@@ -608,7 +682,10 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         csr_pass_kernel<false><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         if (L.range_mode) csr_scan_range_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
         else csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
-        csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
     } else {
         lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
         // stable radix sort by vertex id: equal keys keep ascending entry (= point) order
