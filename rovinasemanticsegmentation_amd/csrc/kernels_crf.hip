@@ -109,21 +109,29 @@ __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long
 // ---------------------------------------------------------------------------------------------
 // Permutohedral::init per point (SSE branch semantics, fp32, no contraction)
 // ---------------------------------------------------------------------------------------------
-constexpr int LP_SET = 1024;       // block-local vertex set (256 points x (d+1) keys, few distinct)
+constexpr int LP_SET = 1024;       // block-local vertex set (LP_CHUNKS x 256 points x (d+1) keys, few distinct)
 constexpr int LP_MAX_PROBE = 24;
+constexpr int LP_CHUNKS = 4;       // consecutive 256-point chunks per block: the set (and its global slots) carries over
 
 template <int D>
 __global__ void __launch_bounds__(256)
 lattice_points_kernel(LatticeDev L, FeatureSource fs) {
-    // block-local vertex set: tag (EMPTY / LOCKED / FILLED), key, global slot
+    // block-local vertex set: tag (EMPTY / LOCKED / FILLED), key, global slot; `lnew` lists the set
+    // entries in creation order, so each chunk resolves only the entries it added
     __shared__ int ltag[LP_SET];
     __shared__ unsigned long long lkey[LP_SET][2];
     __shared__ unsigned lslot[LP_SET];
+    __shared__ unsigned short lnew[LP_SET];
+    __shared__ unsigned n_new;
     for (int t = threadIdx.x; t < LP_SET; t += 256) ltag[t] = ST_EMPTY;
+    if (threadIdx.x == 0) n_new = 0;
     __syncthreads();
-
-    const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    unsigned resolved = 0;   // set entries [0, resolved) of lnew already have their global slot
     const long long per_frame = L.Npad;
+
+  for (int chunk = 0; chunk < LP_CHUNKS; chunk++) {
+    const long long gid0 = ((long long)blockIdx.x * LP_CHUNKS + chunk) * 256 + threadIdx.x;
     const bool active = gid0 < per_frame * L.n_frames;   // all threads stay for the barriers
     const long long gid = active ? gid0 : 0;
     const int frame = (int)(gid / per_frame);
@@ -226,10 +234,26 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
             key.k[k] = (short)(rem0[k] + (float)canon);
         }
         key.k[7] = (short)frame;
-        lidx[r] = 0;
-        if (active) {
+        // equal keys inside the wave first (neighbouring points share most vertices): one lane per
+        // distinct key goes to the LDS set, the others take its answer
+        int leader_of = lane;
+        {
+            bool pending = active;
+            for (;;) {
+                const unsigned long long todo = __ballot(pending);
+                if (!todo) break;
+                const int ld = __ffsll((long long)todo) - 1;
+                const unsigned a0 = __builtin_amdgcn_readlane(key.w[0], ld), a1 = __builtin_amdgcn_readlane(key.w[1], ld);
+                const unsigned a2 = __builtin_amdgcn_readlane(key.w[2], ld), a3 = __builtin_amdgcn_readlane(key.w[3], ld);
+                const bool same = pending && key.w[0] == a0 && key.w[1] == a1 && key.w[2] == a2 && key.w[3] == a3;
+                if (same) leader_of = ld;
+                pending = pending && !same;
+            }
+        }
+        int found = 0;
+        if (active && leader_of == lane) {
             unsigned h = (hash_key(key) >> 7) & (LP_SET - 1);
-            int found = -1;
+            found = -1;
             for (int probes = 0; probes < LP_MAX_PROBE; ) {
                 const int t = __hip_atomic_load(&ltag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (t == ST_EMPTY) {
@@ -239,6 +263,7 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
                         __hip_atomic_store(&lkey[h][0], key.q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(&lkey[h][1], key.q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(&ltag[h], ST_FILLED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        lnew[atomicAdd(&n_new, 1u)] = (unsigned short)h;   // at most LP_SET entries are ever created
                         found = (int)h;
                         break;
                     }
@@ -253,19 +278,20 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
             }
             if (found < 0)  // set too crowded around this key: go to the global table directly
                 found = -1 - (int)hash_insert(L.state, L.tkeys, (unsigned)frame << L.cap_f_log2, L.cap_f_mask, L.counters, key);
-            lidx[r] = found;
         }
+        lidx[r] = __shfl(found, leader_of, 64);
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < LP_SET; t += 256) {
-        if (ltag[t] == ST_FILLED) {
-            Key8 key;
-            key.q[0] = lkey[t][0];
-            key.q[1] = lkey[t][1];
-            const unsigned fr = (unsigned)(unsigned short)key.k[7];
-            lslot[t] = hash_insert(L.state, L.tkeys, fr << L.cap_f_log2, L.cap_f_mask, L.counters, key);
-        }
+    const unsigned created = n_new;   // stable until the next chunk's phase 1, which starts after the barrier below
+    for (unsigned t = resolved + threadIdx.x; t < created; t += 256) {
+        const unsigned h = lnew[t];
+        Key8 key;
+        key.q[0] = lkey[h][0];
+        key.q[1] = lkey[h][1];
+        const unsigned fr = (unsigned)(unsigned short)key.k[7];
+        lslot[h] = hash_insert(L.state, L.tkeys, fr << L.cap_f_log2, L.cap_f_mask, L.counters, key);
     }
+    resolved = created;
     __syncthreads();
     if (real) {
         int so[D + 1];
@@ -277,11 +303,13 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
         store_row<D + 1>(L.offsets + gp * (D + 1), so);
         store_row<D + 1>(L.bary + gp * (D + 1), bary);
     }
+  }
 }
 
 void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s) {
     const long long total = (long long)L.Npad * L.n_frames;
-    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    const long long per_block = 256ll * LP_CHUNKS;
+    const dim3 grid((unsigned)((total + per_block - 1) / per_block)), block(256);
     switch (L.d) {
         case 1: lattice_points_kernel<1><<<grid, block, 0, s>>>(L, fs); break;
         case 2: lattice_points_kernel<2><<<grid, block, 0, s>>>(L, fs); break;
