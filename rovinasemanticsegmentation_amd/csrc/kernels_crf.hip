@@ -744,14 +744,27 @@ vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict
             const unsigned fr = frame / (unsigned)L.n_groups, l16 = len >> 4;
             k = (g << 28) | ((fr < 255u ? fr : 255u) << 20) | (0xFFFFFu - (l16 < 0xFFFFFu ? l16 : 0xFFFFFu));
         }
-        atomicAdd(L.gcount + g, 1u);
     }
     key[v] = k;
     ids[v] = (unsigned)v;
 }
 
+// vertices per launch group = the vertices of its frames (ids are frame-contiguous)
+__global__ void __launch_bounds__(64)
+group_count_kernel(LatticeDev L) {
+    const int g = threadIdx.x;
+    if (g >= L.n_groups) return;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    unsigned n = 0;
+    for (int f = g; f < L.n_frames; f += L.n_groups) {
+        const int a = L.fstart[f] < M ? L.fstart[f] : M, b = L.fstart[f + 1] < M ? L.fstart[f + 1] : M;
+        n += (unsigned)(b - a);
+    }
+    L.gcount[g] = n;
+}
+
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
-    (void)hipMemsetAsync(L.gcount, 0, 8 * sizeof(unsigned), s);
+    group_count_kernel<<<dim3(1), dim3(64), 0, s>>>(L);
     static const int frame_major = getenv("RVSEG_SPLAT_FRAME_MAJOR") ? atoi(getenv("RVSEG_SPLAT_FRAME_MAJOR")) : 0;
     vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, frame_major);
     size_t temp = sb.temp_bytes;
@@ -1263,7 +1276,8 @@ void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long lon
 // slices from there; otherwise it gathers from HBM/L2.  Same operation order as the unfused
 // kernels, so the result is bit-identical.
 // ---------------------------------------------------------------------------------------------
-constexpr int MF_LDS_BYTES = 48 * 1024;
+constexpr int MF_LDS_BYTES = 24 * 1024;   // frames with more vertices than fit read `values` from L2
+constexpr int MF_PTS = 1024;              // points per block (4 per thread): one table load serves them all
 
 template <bool SEQ, int C, int DP1>   // DP1 = d+1 at compile time (wide offset / weight loads), 0 = runtime d
 __global__ void __launch_bounds__(256)
@@ -1272,9 +1286,9 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     extern __shared__ __attribute__((aligned(16))) float tab[];
     if (L.counters[1]) return;   // uniform: hash overflow (flagged)
     constexpr int CP = (C + 3) / 4 * 4;
-    const int bpf = (L.N + 255) / 256;
+    const int bpf = (L.N + MF_PTS - 1) / MF_PTS;
     const int frame = blockIdx.x / bpf;
-    const int i = (blockIdx.x - frame * bpf) * 256 + threadIdx.x;
+    const int i0 = (blockIdx.x - frame * bpf) * MF_PTS + threadIdx.x;
     const int f0 = L.fstart[frame], f1 = L.fstart[frame + 1];
     const int Mf = f1 - f0;
     const bool use_lds = (size_t)Mf * CP * sizeof(float) <= (size_t)MF_LDS_BYTES;
@@ -1285,7 +1299,7 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
         }
         __syncthreads();
     }
-    if (i >= L.N) return;
+  for (int i = i0; i < i0 + MF_PTS && i < L.N; i += 256) {   // the staged table serves MF_PTS points
     const size_t p = (size_t)frame * L.N + i;
     const int dp1 = DP1 > 0 ? DP1 : L.d + 1;
     float acc[C];
@@ -1345,13 +1359,14 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
         for (int c = 0; c < C; c++) b[c] = b[c] * nrm;
     }
     store_row<C>(Q.base + qrow, b);
+  }
 }
 
 // returns false when C has no fused instantiation (the caller then runs the unfused kernels)
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
                       const ValueView& Q, bool scale_out, hipStream_t s) {
     const float alpha = 1.0f / (1 + powf(2, (float)-L.d));
-    const int bpf = (L.N + 255) / 256;
+    const int bpf = (L.N + MF_PTS - 1) / MF_PTS;
     const dim3 grid((unsigned)(bpf * L.n_frames)), block(256);
 #define RV_MF(SEQ, CC)                                                                                            \
     if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0); \
