@@ -297,21 +297,23 @@ float orc_exp_f32(float xf) {
     if (x < -104.0) return 0.0f;
     if (x > 88.8) return INFINITY;
     double n = rint(x * 1.4426950408889634074);
-    double r = (x - n * 6.93147180369123816490e-01) - n * 1.90821492927058770002e-10;
-    double p = 0x1.6124613a86d09p-33;            /* 1/13! */
-    p = p * r + 0x1.1eed8eff8d898p-29;           /* 1/12! */
-    p = p * r + 0x1.ae64567f544e4p-26;           /* 1/11! */
-    p = p * r + 0x1.27e4fb7789f5cp-22;           /* 1/10! */
-    p = p * r + 0x1.71de3a556c734p-19;           /* 1/9!  */
-    p = p * r + 0x1.a01a01a01a01ap-16;           /* 1/8!  */
-    p = p * r + 0x1.a01a01a01a01ap-13;           /* 1/7!  */
-    p = p * r + 0x1.6c16c16c16c17p-10;           /* 1/6!  */
-    p = p * r + 0x1.1111111111111p-7;            /* 1/5!  */
-    p = p * r + 0x1.5555555555555p-5;            /* 1/4!  */
-    p = p * r + 0x1.5555555555555p-3;            /* 1/3!  */
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    /* fma() is part of the definition: IEEE-754 fixes its result, so libm / x86 FMA3 and the GPU's
+     * v_fma_f64 agree bit for bit (independent of -ffp-contract, which only governs a*b+c spelled
+     * with operators) */
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 0x1.ae64567f544e4p-26;            /* 1/11! */
+    p = fma(p, r, 0x1.27e4fb7789f5cp-22);        /* 1/10! */
+    p = fma(p, r, 0x1.71de3a556c734p-19);        /* 1/9!  */
+    p = fma(p, r, 0x1.a01a01a01a01ap-16);        /* 1/8!  */
+    p = fma(p, r, 0x1.a01a01a01a01ap-13);        /* 1/7!  */
+    p = fma(p, r, 0x1.6c16c16c16c17p-10);        /* 1/6!  */
+    p = fma(p, r, 0x1.1111111111111p-7);         /* 1/5!  */
+    p = fma(p, r, 0x1.5555555555555p-5);         /* 1/4!  */
+    p = fma(p, r, 0x1.5555555555555p-3);         /* 1/3!  */
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
     uint64_t bits = (uint64_t)((int64_t)n + 1023) << 52;
     double scale;
     memcpy(&scale, &bits, 8);

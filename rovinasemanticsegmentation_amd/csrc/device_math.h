@@ -41,30 +41,33 @@ __device__ __forceinline__ float acos_f32_dev(float xf) {
 }
 
 // exp for expAndNormalize (third-party/densecrf/src/densecrf.cpp:102): n = rint(x*log2e),
-// two-part ln2 reduction, degree-13 Taylor polynomial in Horner form, exact 2^n scaling.
+// two-part ln2 reduction, degree-11 Taylor polynomial in Horner form, exact 2^n scaling.  The
+// fused multiply-adds are spelled out and part of the definition (IEEE-754 fixes fma, so
+// v_fma_f64 and the host's fma() agree); |r| <= ln2/2 leaves a truncation error below 1e-14.
+// Branch-free: the three special cases are selected at the end.
 __device__ __forceinline__ float exp_f32_dev(float xf) {
-    double x = (double)xf;
-    if (x != x) return xf;
-    if (x < -104.0) return 0.0f;
-    if (x > 88.8) return __int_as_float(0x7f800000);
-    const double n = rint(x * 1.4426950408889634074);
-    const double r = (x - n * 6.93147180369123816490e-01) - n * 1.90821492927058770002e-10;
-    double p = 0x1.6124613a86d09p-33;
-    p = p * r + 0x1.1eed8eff8d898p-29;
-    p = p * r + 0x1.ae64567f544e4p-26;
-    p = p * r + 0x1.27e4fb7789f5cp-22;
-    p = p * r + 0x1.71de3a556c734p-19;
-    p = p * r + 0x1.a01a01a01a01ap-16;
-    p = p * r + 0x1.a01a01a01a01ap-13;
-    p = p * r + 0x1.6c16c16c16c17p-10;
-    p = p * r + 0x1.1111111111111p-7;
-    p = p * r + 0x1.5555555555555p-5;
-    p = p * r + 0x1.5555555555555p-3;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    const double x = (double)xf;
+    const double xc = x < -104.0 ? -104.0 : (x > 88.8 ? 88.8 : x);   // NaN falls through both compares
+    const double n = rint(xc * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, xc);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 0x1.ae64567f544e4p-26;
+    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
     const double scale = __longlong_as_double(((long long)n + 1023) << 52);
-    return (float)(p * scale);
+    float res = (float)(p * scale);
+    res = x < -104.0 ? 0.0f : res;
+    res = x > 88.8 ? __int_as_float(0x7f800000) : res;
+    return x != x ? xf : res;
 }
 
 // Rows of C floats / d+1 ints are only 4-byte aligned; these vector types let the compiler fetch
