@@ -173,6 +173,27 @@ rvseg_status rvseg_lattice_filter(rvseg_ctx *ctx, const float *in, int32_t C, fl
 rvseg_status rvseg_lattice_neighbours(rvseg_ctx *ctx, int32_t *n1_out, int32_t *n2_out, uint32_t *csr_point,
                                       uint32_t *vstart, uint32_t *vend);
 
+/* Local-map fusion -- replaces the accumulation loop of Segmenter::processMapFromQueue,
+ * src/segmenter.cpp:561-616:  unaries[l](c, index) += label_distribution[off_l + pixel*C_l + c]
+ * for every image in call order, pixels in raster order (the order fixes the fp32 sums).
+ *   index_images  n_images x H x W int32, the projector's IndexImage rows of one camera
+ *                 (index_image.ptr<int>(y + i*_camera_h), :601): cloud point seen at the pixel, < 0 = none
+ *   posteriors    n_images x (sum C_l * H * W) floats, each image in the layout rvseg_segment_frames
+ *                 writes ([layer][y][x][class], segmenter.cpp:413-431)
+ *   unaries_out   layers concatenated; layer l is cloud_size x C_l, point-major (== the C_l x cloud_size
+ *                 column-major Eigen matrix of :563-567), starting at cloud_size * (C_0 + .. + C_{l-1})
+ * H, W are the context's.  An index >= cloud_size is RVSEG_ERR_INVALID_ARG (the reference writes out of
+ * bounds).  Feed -unaries_out[l] to rvseg_crf_infer (:642) or label it with the no-CRF rule (:660-681). */
+rvseg_status rvseg_fuse_posteriors(rvseg_ctx *ctx, int32_t n_images, const int32_t *index_images,
+                                   const float *posteriors, int32_t n_layers, const int32_t *class_counts,
+                                   int32_t cloud_size, float *unaries_out);
+
+/* One of the label rules above over a host matrix of N points x C classes (class-contiguous); the
+ * no-CRF branch of processMapFromQueue applies RVSEG_LABEL_NOCRF to the fused unaries
+ * (src/segmenter.cpp:660-681). */
+rvseg_status rvseg_label_values(rvseg_ctx *ctx, const float *values, int32_t N, int32_t C, int32_t label_mode,
+                                int32_t unknown_label, int8_t *labels_out);
+
 /* ---- timing of the last segment_frames / crf_infer call, measured with HIP events on the
  *      stream the kernels ran on.  names_out receives a ';'-separated list of stage names,
  *      ms_out up to max_stages durations.  Returns the number of stages. */

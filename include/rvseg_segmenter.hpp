@@ -14,6 +14,7 @@
 //   processMapFromQueue() CRF branch              :628-658    processCloud(): DenseCRF per layer
 //       label = max marginal > 2.0/C else Unknown :646-657        same rule (RVSEG_LABEL_CRF)
 //   processMapFromQueue() no-CRF branch           :660-681    labelCloud(): RVSEG_LABEL_NOCRF rule
+//   processMapFromQueue() accumulation loop       :561-616    fusePosteriors(), processMap()
 //   srvSegmentationInformation()                  :776-791    srvSegmentationInformation()
 //
 // Thread rule as in the reference: one thread drives one Segmenter (the RF worker owns the frame
@@ -134,20 +135,49 @@ public:
     }
 
     // no-CRF branch (segmenter.cpp:660-681): strict '>' from -1000 with the sum != 0 guard
-    std::vector<unsigned char> labelCloud(size_t layer, size_t cloud_size, const float* unaries) const {
+    std::vector<unsigned char> labelCloud(size_t layer, size_t cloud_size, const float* unaries) {
         const int C = (int)conf_.layers.at(layer).classes.size();
-        std::vector<unsigned char> out(cloud_size);
-        for (size_t i = 0; i < cloud_size; i++) {
-            unsigned best = (unsigned)conf_.layers[layer].unknown_label;
-            float mx = -1000.f, sum = 0.f;
-            for (int c = 0; c < C; c++) {
-                const float v = unaries[i * (size_t)C + c];
-                sum += v;
-                if (v > mx) { mx = v; best = (unsigned)c; }
-            }
-            out[i] = (unsigned char)(sum != 0.0f ? best : (unsigned)conf_.layers[layer].unknown_label);
+        std::vector<int8_t> map(cloud_size);
+        check(rvseg_label_values(ctx_, unaries, (int32_t)cloud_size, C, RVSEG_LABEL_NOCRF, conf_.layers[layer].unknown_label, map.data()));
+        return std::vector<unsigned char>(map.begin(), map.end());
+    }
+
+    // Accumulation loop of processMapFromQueue (segmenter.cpp:561-616): index_images holds one
+    // H x W IndexImage per (map node, camera) that has a segmentation, posteriors the matching
+    // label distributions (processFrames output) in the same order.  Returns unaries[layer], each
+    // C_l x cloud_size column-major like the Eigen matrices of :563-567.
+    std::vector<std::vector<float>> fusePosteriors(int n_images, const int32_t* index_images, const float* posteriors, size_t cloud_size) {
+        std::vector<int32_t> cc;
+        for (const Layer& l : conf_.layers) cc.push_back((int32_t)l.classes.size());
+        std::vector<float> flat(cloud_size * (size_t)total_labels_);
+        check(rvseg_fuse_posteriors(ctx_, n_images, index_images, posteriors, (int32_t)cc.size(), cc.data(), (int32_t)cloud_size, flat.data()));
+        std::vector<std::vector<float>> out(cc.size());
+        size_t off = 0;
+        for (size_t l = 0; l < cc.size(); l++) {
+            out[l].assign(flat.begin() + off, flat.begin() + off + cloud_size * (size_t)cc[l]);
+            off += cloud_size * (size_t)cc[l];
         }
         return out;
+    }
+
+    // processMapFromQueue for one local map (segmenter.cpp:561-682): fusion, then per layer the cloud
+    // CRF (:628-658) or the no-CRF rule (:660-681).  cloud_xyz / cloud_rgb: cloud_size x 3, rgb in [0,1].
+    std::vector<std::vector<unsigned char>> processMap(int n_images, const int32_t* index_images, const float* posteriors,
+                                                       size_t cloud_size, const float* cloud_xyz, const float* cloud_rgb) {
+        const std::vector<std::vector<float>> unaries = fusePosteriors(n_images, index_images, posteriors, cloud_size);
+        std::vector<std::vector<unsigned char>> result_labels(unaries.size());
+        std::vector<float> pairwise;
+        if (conf_.use_dense_crf) {
+            pairwise.resize(cloud_size * 6);
+            for (size_t i = 0; i < cloud_size; i++) {            // segmenter.cpp:629-637
+                for (int k = 0; k < 3; k++) pairwise[i * 6 + k] = cloud_xyz[i * 3 + k] * conf_.dcrf_xyz_kernel;
+                for (int k = 0; k < 3; k++) pairwise[i * 6 + 3 + k] = cloud_rgb[i * 3 + k] * conf_.dcrf_rgb_kernel;
+            }
+        }
+        for (size_t l = 0; l < unaries.size(); l++)
+            result_labels[l] = conf_.use_dense_crf ? processCloud(l, cloud_size, unaries[l].data(), pairwise.data())
+                                                   : labelCloud(l, cloud_size, unaries[l].data());
+        return result_labels;
     }
 
     bool srvSegmentationInformation(SegmentationInformation& resp) const {

@@ -72,6 +72,7 @@ def lib():
         L.orc_extract.argtypes = [C.POINTER(OrcParams), vp, vp, vp, vp, vp, vp]
         L.orc_rf_frame.argtypes = [C.POINTER(OrcParams), vp, ip, vp, vp, vp, vp]
         L.orc_labels.argtypes = [vp, ip, ip, ip, ip, vp]
+        L.orc_fuse_posteriors.argtypes = [ip, ip, ip, vp, vp, ip, vp, ip, vp]
         L.orc_lattice_init.restype = C.POINTER(_Lattice)
         L.orc_lattice_init.argtypes = [vp, ip, ip]
         L.orc_lattice_free.argtypes = [C.POINTER(_Lattice)]
@@ -214,6 +215,17 @@ def labels(values, Cn, mode, unknown=0):
     values = np.ascontiguousarray(values, np.float32).reshape(-1, Cn)
     out = np.empty(values.shape[0], np.int8)
     lib().orc_labels(_p(values), values.shape[0], Cn, mode, unknown, _p(out))
+    return out
+
+
+def fuse_posteriors(index_images, posteriors, class_counts, cloud_size):
+    idx = np.ascontiguousarray(index_images, np.int32)
+    n, H, W = idx.shape
+    S = int(sum(class_counts))
+    post = np.ascontiguousarray(posteriors, np.float32).reshape(n, S * H * W)
+    cc = (C.c_int * len(class_counts))(*class_counts)
+    out = np.empty(cloud_size * S, np.float32)
+    lib().orc_fuse_posteriors(n, W, H, _p(idx), _p(post), len(class_counts), cc, cloud_size, _p(out))
     return out
 
 

@@ -691,6 +691,37 @@ int orc_rf_frame(const orc_params *p, const orc_forest *f, int multi, const uint
     return P;
 }
 
+/* src/segmenter.cpp:561-616.  label_distribution of one image is [layer][y][x][class] (:413-431);
+ * `offset` advances by H*W*C_l per layer (:613), image_index counts pixels in raster order (:598-611). */
+void orc_fuse_posteriors(int n_images, int W, int H, const int32_t *index_images, const float *posteriors, int n_layers,
+                         const int *class_counts, int cloud_size, float *unaries) {
+    size_t S = 0;
+    for (int l = 0; l < n_layers; l++) S += (size_t)class_counts[l];
+    for (size_t i = 0; i < (size_t)cloud_size * S; i++) unaries[i] = 0.0f;      /* Constant(label_count, cloud_size, 0.0), :566 */
+    const size_t pixels = (size_t)W * H;
+    for (int m = 0; m < n_images; m++) {
+        const int32_t *index_image = index_images + (size_t)m * pixels;
+        const float *label_distribution = posteriors + (size_t)m * pixels * S;
+        size_t offset = 0, uoff = 0;
+        for (int l = 0; l < n_layers; l++) {
+            const size_t C = (size_t)class_counts[l];
+            size_t image_index = 0;
+            for (int y = 0; y < H; y++) {
+                for (int x = 0; x < W; x++) {
+                    const int index = index_image[(size_t)y * W + x];
+                    if (index >= 0 && index < cloud_size) {
+                        for (size_t c = 0; c < C; c++)
+                            unaries[uoff + (size_t)index * C + c] += label_distribution[offset + image_index * C + c];   /* :607 */
+                    }
+                    image_index++;
+                }
+            }
+            offset += pixels * C;
+            uoff += (size_t)cloud_size * C;
+        }
+    }
+}
+
 void orc_labels(const float *values, int N, int C, int mode, int unknown_label, int8_t *labels) {
     for (int i = 0; i < N; i++) {
         const float *v = values + (size_t)i * C;

@@ -127,6 +127,11 @@ int orc_rf_frame(const orc_params *p, const orc_forest *f, int multi, const uint
  * mode 3: DenseCRF::currentMap (densecrf.cpp:202-211) first maximum. */
 void orc_labels(const float *values, int N, int C, int mode, int unknown_label, int8_t *labels);
 
+/* local-map fusion, src/segmenter.cpp:561-616: unaries (layers concatenated, layer l = cloud_size x C_l
+ * point-major, zero-initialised) += posteriors through the index images, images in order, raster order */
+void orc_fuse_posteriors(int n_images, int W, int H, const int32_t *index_images, const float *posteriors, int n_layers,
+                         const int *class_counts, int cloud_size, float *unaries);
+
 /* ------------------------------------------------------------------ lattice + CRF (rows N-W) */
 typedef struct orc_lattice {
     int N, d, M;

@@ -21,6 +21,7 @@ SYMBOLS = [
     "rvseg_forest_info", "rvseg_forest_eval", "rvseg_extract_features", "rvseg_segment_frames",
     "rvseg_segment_frames_device", "rvseg_crf_infer", "rvseg_crf_infer_multi",
     "rvseg_lattice_build", "rvseg_lattice_filter", "rvseg_lattice_neighbours", "rvseg_last_timing",
+    "rvseg_fuse_posteriors", "rvseg_label_values",
 ]
 
 
@@ -83,6 +84,8 @@ def lib():
     L.rvseg_segment_frames_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rvseg_crf_infer.argtypes = [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, i32]
     L.rvseg_crf_infer_multi.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32]
+    L.rvseg_fuse_posteriors.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp]
+    L.rvseg_label_values.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.rvseg_lattice_build.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, C.POINTER(i32)]
     L.rvseg_lattice_filter.argtypes = [vp, vp, i32, vp]
     L.rvseg_lattice_neighbours.argtypes = [vp, vp, vp, vp, vp, vp]

@@ -987,9 +987,10 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
             auto load_entries = [&](unsigned tile, int slot) {
                 unsigned k = kc0 + tile * 64u + lane;
                 k = k < kc1 ? k : kc1 - 1u;
-                const uint2 pw = L.csr_pw[k];
-                w[slot] = __uint_as_float(pw.y);
-                pix[slot] = pw.x;
+                // read once per launch: non-temporal, so the stream does not evict the gathered Q rows from L2
+                const unsigned long long pw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(L.csr_pw) + k);
+                w[slot] = __uint_as_float((unsigned)(pw >> 32));
+                pix[slot] = (unsigned)pw;
                 if (MODE == 1) nrm[slot] = L.csr_nrm[k];
             };
             auto gather_rows = [&](int eslot, int rslot) {

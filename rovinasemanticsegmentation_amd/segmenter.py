@@ -142,6 +142,26 @@ class Context:
         capi.check(self.h, self.L.rvseg_crf_infer_multi(self.h, N, Cn, len(feats), ds, ptrs, wsa, _ptr(U), iterations, _ptr(Q), _ptr(mp), label_mode, unknown_label))
         return Q, mp
 
+    # ---- local-map fusion -------------------------------------------------------------------
+    def fuse_posteriors(self, index_images, posteriors, class_counts, cloud_size):
+        p = self.params
+        idx = np.ascontiguousarray(index_images, np.int32)
+        n = idx.shape[0]
+        assert idx.shape == (n, p.height, p.width)
+        S = int(sum(class_counts))
+        post = np.ascontiguousarray(posteriors, np.float32).reshape(n, S * p.height * p.width)
+        cc = (C.c_int32 * len(class_counts))(*class_counts)
+        out = np.empty(cloud_size * S, np.float32)
+        capi.check(self.h, self.L.rvseg_fuse_posteriors(self.h, n, _ptr(idx), _ptr(post), len(class_counts), cc, cloud_size, _ptr(out)))
+        return out
+
+    def label_values(self, values, label_mode, unknown_label=0):
+        V = np.ascontiguousarray(values, np.float32)
+        N, Cn = V.shape
+        out = np.empty(N, np.int8)
+        capi.check(self.h, self.L.rvseg_label_values(self.h, _ptr(V), N, Cn, label_mode, unknown_label, _ptr(out)))
+        return out
+
     def lattice_build(self, features, keys_capacity=None):
         F = np.ascontiguousarray(features, np.float32)
         N, d = F.shape
@@ -267,6 +287,31 @@ class Segmenter:
 
     def processFrames(self, color, depth, calib, **kw):
         return self.ctx.segment_frames(color, depth, calib, **kw)
+
+    def processMap(self, index_images, posteriors, cloud_xyz, cloud_rgb, unknown_labels=None):
+        """The body of processMapFromQueue for one local map (src/segmenter.cpp:561-682): fuse the frames'
+        label distributions into per-point unaries through the index images, then per layer either the
+        cloud DenseCRF with the thresholded argmax (:628-658) or the no-CRF rule (:660-681).
+        cloud_rgb is in [0, 1] like fps_mapper's cloud (:698-700).  Returns (result_labels, unaries)."""
+        p = self.ctx.params
+        cc = self.layer_class_counts
+        cloud_xyz = np.ascontiguousarray(cloud_xyz, np.float32)
+        cloud_rgb = np.ascontiguousarray(cloud_rgb, np.float32)
+        n_pts = cloud_xyz.shape[0]
+        flat = self.ctx.fuse_posteriors(index_images, posteriors, cc, n_pts)
+        offs = np.cumsum([0] + [c * n_pts for c in cc])
+        unaries = [flat[offs[l]:offs[l + 1]].reshape(n_pts, cc[l]) for l in range(len(cc))]
+        unknown = unknown_labels if unknown_labels is not None else [p.unknown_label[l] for l in range(len(cc))]
+        labels = []
+        if p.use_dense_crf:
+            pairwise = np.concatenate([cloud_xyz * np.float32(p.dcrf_xyz_kernel), cloud_rgb * np.float32(p.dcrf_rgb_kernel)], 1)   # :629-637
+            for l in range(len(cc)):
+                _, mp = self.ctx.crf_infer(-unaries[l], pairwise, p.dcrf_kernel_weight, p.dcrf_iterations, capi.LABEL_CRF, unknown[l])
+                labels.append(mp.astype(np.uint8))
+        else:
+            for l in range(len(cc)):
+                labels.append(self.ctx.label_values(unaries[l], capi.LABEL_NOCRF, unknown[l]).astype(np.uint8))
+        return labels, unaries
 
     def close(self):
         self.ctx.close()

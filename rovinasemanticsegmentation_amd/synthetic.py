@@ -9,6 +9,8 @@ README.md:4 of the reference), so every forest and frame is synthetic:
            t = (0,0,0.6)
   * forest T trees grown top-down by random splits, written in the libforest stream format
            (third-party/libforest/src/classifier.cpp:144-152,210-220; io.h:84-96)
+  * local map: a cloud back-projected from frame 0 and pin-hole z-buffer index images -- a stand-in
+           for fps_mapper::MultiProjector::project (src/segmenter.cpp:578), which is not in the tree
 """
 import struct
 
@@ -134,3 +136,49 @@ def random_points(seed, P, D=366):
         X[:, 364] = rng.uniform(-1.0, 3.0, P)
         X[:, 365] = np.where(rng.random(P) < 0.1, -2.0, rng.uniform(0, np.pi / 2, P))
     return X
+
+
+def back_project(depth, calib, W=640, H=480):
+    """(R K^-1) (d x, d y, d) + t for every pixel with depth > 0 (feature_extractor.h:209-223), float64."""
+    c = np.asarray(calib, np.float64)
+    Kinv, R, t = c[:9].reshape(3, 3), c[9:18].reshape(3, 3), c[18:21]
+    ys, xs = np.mgrid[0:H, 0:W]
+    d = depth.astype(np.float64) / 1000.0
+    m = np.stack([d * xs, d * ys, d], -1).reshape(-1, 3)
+    pts = m @ (R @ Kinv).T + t
+    return pts, (depth.ravel() > 0)
+
+
+def project_cloud(cloud_xyz, calib, W=640, H=480, shift=(0.0, 0.0, 0.0)):
+    """Pin-hole z-buffer: IndexImage (int32, -1 = no point) of the cloud seen from the calibration's
+    camera moved by `shift` (base frame).  The nearest point wins a pixel."""
+    c = np.asarray(calib, np.float64)
+    Kinv, R, t = c[:9].reshape(3, 3), c[9:18].reshape(3, 3), c[18:21]
+    K = np.linalg.inv(Kinv)
+    cam = (np.asarray(cloud_xyz, np.float64) - (t + np.asarray(shift, np.float64))) @ R   # R^T (p - t)
+    z = cam[:, 2]
+    ok = z > 0.05
+    uvw = cam @ K.T
+    u = np.rint(uvw[:, 0] / np.where(ok, z, 1.0)).astype(np.int64)
+    v = np.rint(uvw[:, 1] / np.where(ok, z, 1.0)).astype(np.int64)
+    ok &= (u >= 0) & (u < W) & (v >= 0) & (v < H)
+    idx = np.full(H * W, -1, np.int32)
+    order = np.argsort(-z[ok], kind="stable")          # far first, so the nearest point is written last
+    pts = np.nonzero(ok)[0][order]
+    idx[v[pts] * W + u[pts]] = pts.astype(np.int32)
+    return idx.reshape(H, W)
+
+
+def make_local_map(n_frames, W=640, H=480, step=4, seed=1234):
+    """Frames + a cloud (every `step`-th pixel of frame 0, base frame, rgb in [0,1]) + one index image
+    per frame (the camera drifts a few centimetres per frame)."""
+    rgb, depth = make_batch(n_frames, W, H, seed=seed)
+    calib = make_calib(W, H)
+    pts, valid = back_project(depth[0], calib, W, H)
+    sel = np.zeros((H, W), bool)
+    sel[::step, ::step] = True
+    sel = sel.ravel() & valid
+    cloud_xyz = pts[sel].astype(np.float32)
+    cloud_rgb = (rgb[0].reshape(-1, 3)[sel].astype(np.float32) / np.float32(255.0))
+    index_images = np.stack([project_cloud(cloud_xyz, calib, W, H, shift=(0.01 * i, -0.02 * i, 0.005 * i)) for i in range(n_frames)])
+    return rgb, depth, calib, cloud_xyz, cloud_rgb, index_images

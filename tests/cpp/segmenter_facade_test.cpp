@@ -83,6 +83,20 @@ int main(int argc, char** argv) {
             std::fwrite(plain.data(), 1, plain.size(), out);
             off += N * counts[l];
         }
+        // local-map fusion (segmenter.cpp:561-616): the frame is seen twice, once pixel == point and once
+        // mirrored on every third pixel; then the no-CRF labelling of the fused cloud (:660-681)
+        std::vector<int32_t> index_images(2 * N);
+        for (size_t i = 0; i < N; i++) {
+            index_images[i] = (int32_t)i;
+            index_images[N + i] = i % 3 == 0 ? (int32_t)(N - 1 - i) : -1;
+        }
+        std::vector<float> two(2 * post[0].size());
+        std::memcpy(two.data(), post[0].data(), post[0].size() * 4);
+        std::memcpy(two.data() + post[0].size(), post[0].data(), post[0].size() * 4);
+        auto unaries = seg.fusePosteriors(2, index_images.data(), two.data(), N);
+        auto fused_labels = seg.processMap(2, index_images.data(), two.data(), N, nullptr, nullptr);   // conf.use_dense_crf == false
+        for (size_t l = 0; l < 2; l++) std::fwrite(unaries[l].data(), 4, unaries[l].size(), out);
+        for (size_t l = 0; l < 2; l++) std::fwrite(fused_labels[l].data(), 1, fused_labels[l].size(), out);
         std::fclose(out);
         std::printf("facade ok\n");
         return 0;

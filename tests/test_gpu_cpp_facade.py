@@ -31,7 +31,10 @@ def test_cpp_segmenter_facade(tmp_path, oracle, golden_dir):
     raw = np.fromfile(out_path, np.uint8)
     post = raw[: 17 * N * 4].view(np.float32)
     pairwise = raw[17 * N * 4: 17 * N * 4 + 6 * N * 4].view(np.float32).reshape(N, 6)
-    labels = raw[17 * N * 4 + 6 * N * 4:].reshape(2, 2, N)   # [layer][crf, plain][N]
+    o1 = 17 * N * 4 + 6 * N * 4
+    labels = raw[o1:o1 + 4 * N].reshape(2, 2, N)   # [layer][crf, plain][N]
+    fused = raw[o1 + 4 * N:o1 + 4 * N + 17 * N * 4].view(np.float32)
+    fused_labels = raw[o1 + 4 * N + 17 * N * 4:].reshape(2, N)
 
     forest = oracle.Forest(forest_path)
     p = oracle.default_params(width=W, height=H)
@@ -43,4 +46,14 @@ def test_cpp_segmenter_facade(tmp_path, oracle, golden_dir):
         Q = oracle.crf_inference(-un, pairwise, 10.0, 3)
         assert np.array_equal(labels[l, 0].view(np.int8), oracle.labels(Q, C, 1, unknown=C - 1))
         assert np.array_equal(labels[l, 1].view(np.int8), oracle.labels(un, C, 2, unknown=C - 1))
+        off += N * C
+    # fusion of the frame seen twice (segmenter.cpp:561-616) and the no-CRF cloud labels (:660-681)
+    idx = np.empty((2, N), np.int32)
+    idx[0] = np.arange(N)
+    idx[1] = np.where(np.arange(N) % 3 == 0, N - 1 - np.arange(N), -1)
+    want = oracle.fuse_posteriors(idx.reshape(2, H, W), np.stack([want_post, want_post]), [8, 9], N)
+    assert np.array_equal(fused, want)
+    off = 0
+    for l, C in enumerate((8, 9)):
+        assert np.array_equal(fused_labels[l].view(np.int8), oracle.labels(want[off:off + N * C].reshape(N, C), C, 2, unknown=C - 1))
         off += N * C
