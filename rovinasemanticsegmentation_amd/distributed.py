@@ -4,6 +4,12 @@ Frames are independent (src/segmenter.cpp:340-434 touches no cross-frame state),
 of F key frames is cut into contiguous blocks, one per rank, with no data-path collective.  The
 only exchange is the final label fusion: every rank sends its `uint8/int8[frames][L][H][W]` labels
 to the fusion rank.  Backend-agnostic (`nccl` = RCCL over xGMI on the GPUs, `gloo` in CPU tests).
+
+The reference's own fusion adds fp32 posteriors per cloud point in frame order
+(src/segmenter.cpp:599-616).  For that variant gather the posteriors instead (`gather_frames`, 36x the
+bytes) and run `Segmenter.processMap` / `rvseg_fuse_posteriors` on the fusion rank: the gathered
+tensor is in global frame order, so the sums run in the same order as on one GPU.  An all-reduce
+would be ring-bound and would change the fp32 order.
 """
 import torch
 import torch.distributed as dist
@@ -42,3 +48,8 @@ def gather_labels(local_labels, n_frames_total, dst=0, group=None):
     if rank != dst:
         return None
     return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0)
+
+
+def gather_frames(local_block, n_frames_total, dst=0, group=None):
+    """`gather_labels` for any per-frame tensor (e.g. fp32 posteriors `[count_r, S*H*W]`)."""
+    return gather_labels(local_block, n_frames_total, dst=dst, group=group)

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rovinasemanticsegmentation_amd.distributed import gather_labels, shard_frames
+from rovinasemanticsegmentation_amd.distributed import gather_frames, gather_labels, shard_frames
 
 
 def test_shard_frames_partition():
@@ -59,6 +59,41 @@ def test_label_gather_gloo(world, n_frames):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def _fusion_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        H, W, cc, P = 4, 6, [3, 2], 9
+        rng = np.random.default_rng(11)
+        post_all = (rng.standard_normal((n_frames, sum(cc) * H * W)) * 10.0 ** rng.integers(-2, 7, (n_frames, sum(cc) * H * W))).astype(np.float32)
+        idx_all = rng.integers(-1, P, (n_frames, H, W)).astype(np.int32)
+        start, count = shard_frames(n_frames, rank, world)
+        fused_post = gather_frames(torch.from_numpy(post_all[start:start + count].copy()), n_frames, dst=0)
+        if rank == 0:
+            from oracle import oracle   # the checker: rank 0 fuses the gathered posteriors in frame order
+            got = oracle.fuse_posteriors(idx_all, fused_post.numpy(), cc, P)
+            want = oracle.fuse_posteriors(idx_all, post_all, cc, P)
+            q.put(bool(np.array_equal(got, want)) and bool(np.array_equal(fused_post.numpy(), post_all)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_posterior_gather_keeps_the_fusion_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fusion_worker, args=(r, 2, port, 5, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
