@@ -941,7 +941,7 @@ constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is 
 
 template <int MODE, int CC, bool FULL>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
 __global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64)
-splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
+splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int band) {
     constexpr int G = SplatGroup<CC>::G;
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
@@ -962,7 +962,15 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
             const unsigned idx = j * G + i;
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
-                const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+                unsigned k0 = L.vstart[v], k1 = L.vend[v];
+                if (L.n_bands > 1) {   // this launch sums the list's piece inside band `band`; `values` carries the chain
+                    const int f = (int)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
+                    const int f0 = L.fstart[f], Mf = L.fstart[f + 1] - f0;
+                    const unsigned* fb = L.bh + (size_t)L.wbpf * f0 + ((int)v - f0);
+                    const int w0 = band * L.band_wb, w1 = w0 + L.band_wb;
+                    k0 = fb[(size_t)w0 * Mf];
+                    if (w1 < L.wbpf) k1 = fb[(size_t)w1 * Mf];
+                }
                 const unsigned nt = (k1 - k0 + 63u) / 64u;
                 n_steps = nt > n_steps ? nt : n_steps;
                 if (i == wave) { my_k0 = k0; my_k1 = k1; }
@@ -987,10 +995,9 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
             auto load_entries = [&](unsigned tile, int slot) {
                 unsigned k = kc0 + tile * 64u + lane;
                 k = k < kc1 ? k : kc1 - 1u;
-                // read once per launch: non-temporal, so the stream does not evict the gathered Q rows from L2
-                const unsigned long long pw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(L.csr_pw) + k);
-                w[slot] = __uint_as_float((unsigned)(pw >> 32));
-                pix[slot] = (unsigned)pw;
+                const uint2 pw = L.csr_pw[k];
+                w[slot] = __uint_as_float(pw.y);
+                pix[slot] = pw.x;
                 if (MODE == 1) nrm[slot] = L.csr_nrm[k];
             };
             auto gather_rows = [&](int eslot, int rslot) {
@@ -1040,7 +1047,11 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
         } else {
             // ---- adder: lane (i, c) owns the chain of vertex i, class c
             const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
+            const unsigned idx = j * G + gi;
+            const bool mine = lane < G * CC && idx < n_vert && c < n_store;
+            const unsigned cv = mine ? L.vorder[gstart + idx] : 0u;
             float acc = 0.0f;
+            if (band > 0 && mine) acc = values[(size_t)cv * C + c0 + c];   // running sum of the earlier bands
             __syncthreads();
             for (unsigned t = 0; t < n_steps; t++) {
                 const float* pr = prod[t & 1u][gi][c];
@@ -1051,11 +1062,7 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
                 for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
                 __syncthreads();
             }
-            const unsigned idx = j * G + gi;
-            if (lane < G * CC && idx < n_vert && c < n_store) {
-                const unsigned v = L.vorder[gstart + idx];
-                values[(size_t)v * C + c0 + c] = acc;
-            }
+            if (mine) values[(size_t)cv * C + c0 + c] = acc;
         }
     }
 }
@@ -1065,8 +1072,10 @@ static void splat_group_launch(const LatticeDev& L, const ValueView& src, int C,
     constexpr int G = SplatGroup<CC>::G;
     const unsigned per_group = (L.splat_grid / (unsigned)L.n_groups + G - 1) / G;
     const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
-    if (n == CC) splat_group_kernel<MODE, CC, true><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
-    else splat_group_kernel<MODE, CC, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    for (int band = 0; band < L.n_bands; band++) {
+        if (n == CC) splat_group_kernel<MODE, CC, true><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
+        else splat_group_kernel<MODE, CC, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
+    }
 }
 
 template <int MODE>
@@ -1157,8 +1166,66 @@ blur_kernel(LatticeDev L, int axis, int C, const float* __restrict__ old_v, floa
     }
 }
 
+// All d+1 axis passes of one frame in one block: the frame's vertex values (M_f x C, ~10 KB for the
+// Segmenter kernel) ping-pong between two LDS tables, so a filter costs one launch instead of d+1
+// launch-latency-bound ones.  Frames whose values do not fit go through global memory, still inside
+// the block (a vertex's neighbours belong to its own frame).  The result lands in `b`.
+constexpr int BLUR_LDS_FLOATS = 6144;   // per table
+
+template <bool SEQ>
+__global__ void __launch_bounds__(1024)
+blur_frames_kernel(LatticeDev L, int C, int reverse, float* __restrict__ a, float* __restrict__ b) {
+    __shared__ float tab[2][BLUR_LDS_FLOATS];
+    if (L.counters[1]) return;
+    const int frame = blockIdx.x;
+    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int f0 = L.fstart[frame] < M ? L.fstart[frame] : M, f1 = L.fstart[frame + 1] < M ? L.fstart[frame + 1] : M;
+    const int n = (f1 - f0) * C;
+    const bool lds = n <= BLUR_LDS_FLOATS;
+    float* ga = a + (size_t)f0 * C;
+    float* gb = b + (size_t)f0 * C;
+    if (lds) {
+        for (int i = threadIdx.x; i < n; i += 1024) tab[0][i] = ga[i];
+        __syncthreads();
+    }
+    int cur = 0;
+    for (int t = 0; t <= L.d; t++) {
+        const int axis = reverse ? L.d - t : t;
+        const int* n1p = L.nb1 + (size_t)axis * L.m_bound + f0;
+        const int* n2p = L.nb2 + (size_t)axis * L.m_bound + f0;
+        const float* old_v = lds ? tab[cur] : (cur ? gb : ga);
+        float* new_v = lds ? tab[cur ^ 1] : (cur ? ga : gb);
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int v = i / C, c = i - v * C;
+            const int n1 = n1p[v], n2 = n2p[v];
+            const float x = n1 >= 0 ? old_v[(n1 - f0) * C + c] : 0.0f;
+            const float y = n2 >= 0 ? old_v[(n2 - f0) * C + c] : 0.0f;
+            const float o = old_v[i];
+            if (SEQ) {
+                new_v[i] = (float)((double)o + 0.5 * (double)(x + y));  // seqCompute :505
+            } else {
+                const float sum = x + y;
+                const float h = 0.5f * sum;
+                new_v[i] = o + h;                                        // sseCompute :566
+            }
+        }
+        __syncthreads();   // block-wide: also orders the global-memory path (one block owns the frame)
+        cur ^= 1;
+    }
+    if (lds) {
+        for (int i = threadIdx.x; i < n; i += 1024) gb[i] = tab[cur][i];
+    } else if (cur == 0) {
+        for (int i = threadIdx.x; i < n; i += 1024) gb[i] = ga[i];
+    }
+}
+
 // runs the d+1 axis passes; returns the buffer that holds the result
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s) {
+    if (L.cap_f_mask + 1 <= 8192u) {   // at most 4096 vertices per frame: one block per frame is enough
+        if (seq) blur_frames_kernel<true><<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
+        else blur_frames_kernel<false><<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
+        return b;
+    }
     const long long total = (long long)L.m_bound * C;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     float *cur = a, *nxt = b;

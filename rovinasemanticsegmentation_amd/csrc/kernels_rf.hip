@@ -7,6 +7,8 @@
 // The node array is the breadth-first re-layout built by forest_model.cpp: 16-byte nodes, one
 // dwordx4 load per visited node, the hot top levels of every tree packed at the front of each
 // tree's block so that they stay in L1/L2.
+#include <cstdlib>
+
 #include "device_math.h"
 #include "rvseg_internal.h"
 #include "rvseg_kernels.h"
@@ -281,6 +283,151 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
     }
 }
 
+// =============================================================================================
+// Frame path, on-demand features (the default).  PMC on the kernel above: vector-ALU bound, and 85 %
+// of it is phase B, which resizes all 121 x 3 patch values of every point although a walk through
+// T trees of depth <= 31 tests only ~20 per tree.  Here the lanes are (point, tree) pairs from the
+// start and a patch value is computed when a node asks for it: one channel of one cv::resize cell
+// = 2 LDS weight records + two 8-byte tap loads + ~25 integer ops -- the same arithmetic as phase B.
+// A node's two children are adjacent, so both are fetched together with the taps of the node's
+// own test: still one memory round trip per level.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes, const int32_t* __restrict__ roots,
+                      const float* __restrict__ hist, int n_trees, const ResizeRow* __restrict__ rt, int rt_in_lds,
+                      const uint32_t* __restrict__ lab_all, const uint16_t* __restrict__ depth_all,
+                      const float4* __restrict__ cloud_all, const float* __restrict__ nfeat_all,
+                      float* __restrict__ low_all, int n_points_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ResizeRow* rtl = rt;
+    if (rt_in_lds) {
+        // weight records of every ROI size, 256 B per row
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        const uint4* src = reinterpret_cast<const uint4*>(rt);
+        for (int i = threadIdx.x; i < g.rt_rows * (int)(sizeof(ResizeRow) / 16); i += 256) dst[i] = src[i];
+        __syncthreads();
+        rtl = reinterpret_cast<const ResizeRow*>(smem);
+    }
+    const int lane = threadIdx.x & 63;
+    const int per_frame = g.lw * g.lh;
+    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+    const int W = g.W, H = g.H;
+    const int pt = lane >> 2, sub = lane & 3;
+    const int pid = base + pt;
+
+    // per-point state (mask rule feature_extractor.h:60; half size :139-140), once per lane
+    bool valid = false;
+    int half = 0, x = 0, y = 0, frame = 0;
+    float depth_m = 0.f, height = 0.f, nrm = 0.f;
+    if (pid < n_points_total) {
+        frame = pid / per_frame;
+        const int p = pid - frame * per_frame;
+        const int ly = p / g.lw, lx = p - ly * g.lw;
+        y = ly * g.stride; x = lx * g.stride;
+        const size_t pix = (size_t)frame * W * H + (size_t)y * W + x;
+        const float dv = (float)depth_all[pix];
+        valid = dv >= g.dmin_mm && dv <= g.dmax_mm;
+        depth_m = dv / 1000.0f;
+        if (valid) {
+            half = (int)((double)g.patch_size / (2.0 * (double)depth_m));
+            if (g.pos_height >= 0) height = cloud_all[pix].z;
+            if (g.pos_normal >= 0) nrm = nfeat_all[pid];
+        }
+    }
+    const int size = 2 * half + 1, x0 = x - half, y0 = y - half;
+    const uint32_t* lab = lab_all + (size_t)frame * W * H;
+    const ResizeRow* myrt = rtl + (valid ? half : 0);
+    typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+    // one value of the r x r x 3 patch vector: cv::resize(ROI -> r x r) in 11-bit fixed point
+    // (feature_extractor.h:142), exactly phase B of the kernel above for cell k, channel c
+    auto patch_value = [&](int f) -> float {
+        const int k = f / 3, c = f - 3 * k;
+        const int dy = k / g.r, dx = k - dy * g.r;
+        const uint2 xr = *reinterpret_cast<const uint2*>(&myrt->x[dx]);
+        const uint2 yr = *reinterpret_cast<const uint2*>(&myrt->y[dy]);
+        const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
+        const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
+        const int sx1 = sx0 + 1 < size ? sx0 + 1 : sx0;
+        int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = sy0 + 1;
+        sy0 = sy0 < 0 ? 0 : (sy0 >= size ? size - 1 : sy0);
+        sy1 = sy1 < 0 ? 0 : (sy1 >= size ? size - 1 : sy1);
+        const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
+        const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
+        int xb = rx0 < rx1 ? rx0 : rx1;
+        xb = xb < W - 1 ? xb : W - 2;
+        const u32x2_u q0 = *reinterpret_cast<const u32x2_u*>(lab + (size_t)ry0 * W + xb);
+        const u32x2_u q1 = *reinterpret_cast<const u32x2_u*>(lab + (size_t)ry1 * W + xb);
+        const uint32_t p00 = rx0 == xb ? q0.x : q0.y, p01 = rx1 == xb ? q0.x : q0.y;
+        const uint32_t p10 = rx0 == xb ? q1.x : q1.y, p11 = rx1 == xb ? q1.x : q1.y;
+        const int sh = 8 * c;
+        const int r0 = (int)((p00 >> sh) & 255u) * ia0 + (int)((p01 >> sh) & 255u) * ia1;
+        const int r1 = (int)((p10 >> sh) & 255u) * ia0 + (int)((p11 >> sh) & 255u) * ia1;
+        int v = (((ib0 * (r0 >> 4)) >> 16) + ((ib1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        return (float)v;
+    };
+
+    // lanes = (point, tree); findLeafNode (classifier.cpp:97-117)
+    int leaf_rows[16];
+    int n_mine = 0;
+    const int4* np = reinterpret_cast<const int4*>(nodes);
+    for (int t = sub; t < n_trees; t += 4) {
+        int row = 0;
+        if (valid) {
+            int4 nd = np[roots[t]];
+            while (nd.z != 0) {
+                // both children travel while the node's own test is evaluated
+                const int4 c0 = np[nd.z], c1 = np[nd.z + 1];
+                const int f = nd.x;
+                float v;
+                if (f < g.n_patch) v = patch_value(f);
+                else v = f == g.pos_depth ? depth_m : (f == g.pos_height ? height : nrm);
+                nd = (v < __int_as_float(nd.y)) ? c0 : c1;
+            }
+            row = nd.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) if (q == n_mine) leaf_rows[q] = row;
+        n_mine++;
+    }
+
+    // tree-order accumulation (classifier.cpp:193-206) and scatter into the low-res image at
+    // (y/stride, x/stride) (segmenter.cpp:369-375); invalid cells get the fill value
+    const int lane_base = lane & ~3;
+    const int p = pid - frame * per_frame;
+    for (int c0 = 0; c0 < cm.S; c0 += 4) {
+        const int c = c0 + sub;
+        const int cc = c < cm.S ? c : cm.S - 1;
+        float acc = 0.f;
+        // four leaf rows at a time: the loads are unconditional (invalid points read row 0) and go out
+        // together; the adds stay in tree order
+        for (int t0 = 0; t0 < n_trees; t0 += 4) {
+            float h[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u < n_trees ? t0 + u : n_trees - 1;
+                const int slot = t >> 2;
+                int row = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) if (q == slot) row = leaf_rows[q];
+                row = __shfl(row, lane_base + (t & 3), 64);
+                h[u] = hist[(size_t)row * cm.S + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (t0 + u < n_trees) acc = (t0 + u == 0) ? h[u] : acc + h[u];
+            }
+        }
+        if (pid < n_points_total && c < cm.S) {
+            float* low = low_all + (size_t)frame * per_frame * cm.S;
+            low[cm.layer_base[c] + (size_t)p * cm.layer_C[c] + cm.cl[c]] = valid ? acc : g.fill;
+        }
+    }
+}
+
+static bool n_trees_ok(int n_trees) { return n_trees >= 1 && n_trees <= 64; }   // leaf_rows[16] x 4 lanes per point
+
 void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow* d_rt, const uint32_t* d_lab,
                       const uint16_t* d_depth, const float4* d_cloud, const float* d_nfeat, float* d_low,
                       float* d_dump, uint8_t* d_valid, int n, hipStream_t s) {
@@ -302,6 +449,15 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
     const size_t smem = (size_t)WAVES_PER_BLOCK * (PPW * fb_stride + PPW * 32);
     const int pts_per_block = PPW * WAVES_PER_BLOCK;
     const dim3 grid((unsigned)((total + pts_per_block - 1) / pts_per_block)), block(64 * WAVES_PER_BLOCK);
+    static const bool eager = getenv("RVSEG_RF_EAGER") && atoi(getenv("RVSEG_RF_EAGER")) != 0;   // A/B timing only
+    if (!d_dump && !eager && n_trees_ok(f.n_trees) && !g.debug_skip) {
+        const size_t rt_bytes = (size_t)g.rt_rows * sizeof(ResizeRow);
+        const int in_lds = g.n_patch > 0 && rt_bytes <= 40 * 1024 ? 1 : 0;   // else the records come through L1
+        rf_frames_lazy_kernel<<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(
+            g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(), f.n_trees, d_rt, in_lds, d_lab, d_depth,
+            d_cloud, d_nfeat, d_low, total);
+        return;
+    }
     if (d_dump)
         rf_frames_kernel<true><<<grid, block, smem, s>>>(g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(),
                                                          f.n_trees, d_rt, d_lab, d_depth, d_cloud, d_nfeat, d_low, d_dump, d_valid, total, fb_stride);

@@ -44,6 +44,12 @@ struct LatticeDev {
     uint4* plist;                // per (range, frame group): non-empty pieces {vertex, start, length, -}
     unsigned* pcount;            // per (range, frame group): number of pieces
     unsigned pcap;               // capacity of one piece list
+    // banded splat (counting-sort path): after the scan, bh[wave-block][vertex] is the position of the
+    // vertex's first entry at or after that wave-block, i.e. the vertex-major lists can be cut at any
+    // multiple of CS_PIX points without another sort
+    const unsigned* bh;          // per frame a dense [wbpf][M_f] matrix starting at wbpf * fstart[frame]; null on the radix path
+    int wbpf;                    // wave-blocks per frame
+    int n_bands, band_wb;        // bands per frame (1 = whole lists) and wave-blocks per band
     float* norm;                 // per point, pairwise.cpp:55-56
 };
 

@@ -142,9 +142,20 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.scan_temp = b.scan_temp.p; b.sb.scan_temp_bytes = stemp;
     b.sb.block_hist = nullptr;
     L.range_mode = 0; L.range_wb = 0; L.n_ranges = 0; L.range_grid = 0; L.plist = nullptr; L.pcount = nullptr; L.pcap = 0;
+    L.bh = nullptr; L.wbpf = 0; L.n_bands = 1; L.band_wb = 0;
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
         b.sb.block_hist = b.block_hist.as<unsigned>();
+        {
+            const int pixb = csr_pix_per_block();
+            L.bh = b.sb.block_hist;
+            L.wbpf = (N + pixb - 1) / pixb;
+            const char* be = std::getenv("RVSEG_SPLAT_BANDS");
+            int nb = be ? std::atoi(be) : 1;
+            nb = nb < 1 ? 1 : (nb > L.wbpf ? L.wbpf : nb);
+            L.band_wb = (L.wbpf + nb - 1) / nb;
+            L.n_bands = (L.wbpf + L.band_wb - 1) / L.band_wb;
+        }
         // Large frames: order the entries (range, vertex, point) and splat range by range, so that the
         // d+1 readers of a Q row run at the same time and share it in L2.
         const char* env = std::getenv("RVSEG_SPLAT_RANGE");

@@ -62,6 +62,7 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
     g.D = pos;
     g.fill = p.fill_value;
     g.debug_skip = std::getenv("RVSEG_DEBUG_SKIP") ? std::atoi(std::getenv("RVSEG_DEBUG_SKIP")) : 0;
+    g.rt_rows = 0;
 
     rvseg_status st;
     // 8-bit patch resize tables, one row per ROI half size
@@ -87,6 +88,7 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
             }
         }
         if ((st = upload(ctx, im->resize_rows, rows.data(), rows.size() * sizeof(ResizeRow))) != RVSEG_OK) return st;
+        g.rt_rows = (int)rows.size();
     }
     // float up-sampling tables
     {
