@@ -290,8 +290,9 @@ normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const u
 // entirely out of LDS.  Same integer sums, so the result is identical to the gather kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int NF_TY = 8, NF_TX = 16, NF_APRON = 6;
+constexpr int NF_PARTS = 4;   // lanes per sample point: each sums every 4th window row (integer sums: any order)
 
-__global__ void __launch_bounds__(NF_TY * NF_TX)
+__global__ void __launch_bounds__(NF_TY * NF_TX * NF_PARTS)
 normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const uint8_t* __restrict__ rect_all,
                             float* __restrict__ nfeat_all, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) long long grad[];   // [th*tw][6], then flags
@@ -305,7 +306,7 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
     const int px0 = tx * NF_TX * s - NF_APRON, py0 = ty * NF_TY * s - NF_APRON;   // pixel of LDS cell (0,0)
     const float4* cloud = cloud_all + (size_t)frame * W * H;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < th * tw; idx += NF_TY * NF_TX) {
+    for (int idx = tid; idx < th * tw; idx += NF_TY * NF_TX * NF_PARTS) {
         const int ly = idx / tw, lx = idx - ly * tw;
         const int y = py0 + ly, x = px0 + lx;
         long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
@@ -326,42 +327,53 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
         flags[idx] = fl;
     }
     __syncthreads();
-    const int sy = tid / NF_TX, sx = tid - sy * NF_TX;
+    const int sample = tid / NF_PARTS, part = tid - sample * NF_PARTS;   // the NF_PARTS lanes of a sample are adjacent
+    const int sy = sample / NF_TX, sx = sample - sy * NF_TX;
     const int ly_s = ty * NF_TY + sy, lx_s = tx * NF_TX + sx;   // sample grid coordinates
-    if (ly_s >= g.lh || lx_s >= g.lw) return;
+    const bool inside = ly_s < g.lh && lx_s < g.lw;
     const int ri = ly_s * s, ci = lx_s * s;
-    float out = -2.0f;
     const int border = 10;
-    if (ri >= border && ri < H - border && ci >= border && ci < W - border) {
-        const int rect = rect_all[(size_t)frame * W * H + (size_t)ri * W + ci];
+    int rect = 0;
+    if (inside && ri >= border && ri < H - border && ci >= border && ci < W - border) {
+        rect = rect_all[(size_t)frame * W * H + (size_t)ri * W + ci];
         const float zc = cloud[(size_t)ri * W + ci].z;
-        if (rect > 0 && finite_f(zc)) {
-            const int rect2 = rect >> 1;
-            const int wx = ci - rect2 - px0, wy = ri - rect2 - py0;   // window origin inside the tile
-            long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
-            int cnt_x = 0, cnt_y = 0;
-            for (int yy = wy; yy < wy + rect; yy++) {
-                for (int xx = wx; xx < wx + rect; xx++) {
-                    const int idx = yy * tw + xx;
-                    const long long* d = grad + (size_t)idx * 6;
-                    const unsigned char fl = flags[idx];
-                    cnt_x += fl & 1; cnt_y += (fl >> 1) & 1;
-                    gx0 += d[0]; gx1 += d[1]; gx2 += d[2]; gy0 += d[3]; gy1 += d[4]; gy2 += d[5];
-                }
+        if (!finite_f(zc)) rect = 0;
+    }
+    long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
+    int cnt_x = 0, cnt_y = 0;
+    if (rect > 0) {
+        const int rect2 = rect >> 1;
+        const int wx = ci - rect2 - px0, wy = ri - rect2 - py0;   // window origin inside the tile
+        for (int yy = wy + part; yy < wy + rect; yy += NF_PARTS) {
+            for (int xx = wx; xx < wx + rect; xx++) {
+                const int idx = yy * tw + xx;
+                const long long* d = grad + (size_t)idx * 6;
+                const unsigned char fl = flags[idx];
+                cnt_x += fl & 1; cnt_y += (fl >> 1) & 1;
+                gx0 += d[0]; gx1 += d[1]; gx2 += d[2]; gy0 += d[3]; gy1 += d[4]; gy2 += d[5];
             }
-            if (cnt_x > 0 && cnt_y > 0) {
-                const double k = 1.0 / 4294967296.0;
-                const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
-                const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
-                const double n0 = GY1 * GX2 - GY2 * GX1;
-                const double n1 = GY2 * GX0 - GY0 * GX2;
-                const double n2 = GY0 * GX1 - GY1 * GX0;
-                const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
-                if (len2 != 0.0) {
-                    const float nz = (float)(n2 / sqrt(len2));
-                    if (nz == nz) out = acos_f32_dev(fabsf(nz));
-                }
-            }
+        }
+    }
+    // the four partial sums of a sample sit in adjacent lanes of one wave
+#pragma unroll
+    for (int m = 1; m < NF_PARTS; m <<= 1) {
+        gx0 += __shfl_xor(gx0, m, 64); gx1 += __shfl_xor(gx1, m, 64); gx2 += __shfl_xor(gx2, m, 64);
+        gy0 += __shfl_xor(gy0, m, 64); gy1 += __shfl_xor(gy1, m, 64); gy2 += __shfl_xor(gy2, m, 64);
+        cnt_x += __shfl_xor(cnt_x, m, 64); cnt_y += __shfl_xor(cnt_y, m, 64);
+    }
+    if (!inside || part != 0) return;
+    float out = -2.0f;
+    if (rect > 0 && cnt_x > 0 && cnt_y > 0) {
+        const double k = 1.0 / 4294967296.0;
+        const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
+        const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
+        const double n0 = GY1 * GX2 - GY2 * GX1;
+        const double n1 = GY2 * GX0 - GY0 * GX2;
+        const double n2 = GY0 * GX1 - GY1 * GX0;
+        const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
+        if (len2 != 0.0) {
+            const float nz = (float)(n2 / sqrt(len2));
+            if (nz == nz) out = acos_f32_dev(fabsf(nz));
         }
     }
     nfeat_all[(size_t)frame * g.lw * g.lh + (size_t)ly_s * g.lw + lx_s] = out;
@@ -390,7 +402,7 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
     const size_t lds = (size_t)tw * th * 49;
     if (lds <= 64 * 1024) {
         const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
-        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_TY * NF_TX), lds, s>>>(
+        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_TY * NF_TX * NF_PARTS), lds, s>>>(
             g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y);
         return;
     }
