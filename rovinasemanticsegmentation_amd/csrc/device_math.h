@@ -114,6 +114,32 @@ __device__ __forceinline__ void store_row(T* __restrict__ p, const T* __restrict
     if (i < N) p[i] = in[i];
 }
 
+// The four label rules (rvseg_label_mode in include/rvseg.h) over one point's C class values:
+//   0 eval tool   src/test.cpp:160-175       strict '>' from -1000, -1 when nothing wins
+//   1 CRF         src/segmenter.cpp:646-657  strict '>' from 2.0/C, else the layer's "Unknown"
+//   2 no CRF      src/segmenter.cpp:664-679  strict '>' from -1000, "Unknown" unless the sum is non-zero
+//   3 arg max     densecrf.cpp:202-211       first maximum
+__device__ __forceinline__ int label_rule(const float* v, int C, int mode, int unknown) {
+    int best;
+    float mx;
+    if (mode == 0) {
+        best = -1; mx = -1000.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == 1) {
+        best = unknown; mx = (float)(2.0 / (double)C);
+        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    } else if (mode == 2) {
+        best = unknown; mx = -1000.f;
+        float sum = 0.f;
+        for (int c = 0; c < C; c++) { const float x = v[c]; sum += x; if (x > mx) { mx = x; best = c; } }
+        if (!(sum != 0.0f)) best = unknown;
+    } else {
+        best = 0; mx = v[0];
+        for (int c = 1; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
+    }
+    return best;
+}
+
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
 }  // namespace rvseg

@@ -1347,10 +1347,97 @@ void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long lon
 constexpr int MF_LDS_BYTES = 24 * 1024;   // frames with more vertices than fit read `values` from L2
 constexpr int MF_PTS = 1024;              // points per block (4 per thread): one table load serves them all
 
+// inputs of one point of the update: fetched one point ahead of their use
+template <int C, int DP1>
+struct MfIn {
+    int offs[DP1 > 0 ? DP1 : 1];
+    float wts[DP1 > 0 ? DP1 : 1];
+    float ur[C];
+    float nrm;
+};
+
+template <int C, int DP1>
+__device__ __forceinline__ void mf_load(const LatticeDev& L, const ValueView& unary, int f0, size_t p, MfIn<C, DP1>& in) {
+    if (DP1 > 0) {
+        load_row<(DP1 > 0 ? DP1 : 1)>(L.offsets + p * DP1, in.offs);
+        load_row<(DP1 > 0 ? DP1 : 1)>(L.bary + p * DP1, in.wts);
+    }
+    in.nrm = L.norm[p];
+    load_row<C>(unary.base + unary.index((unsigned)p, 0, C, L.N), in.ur);
+}
+
+template <bool SEQ, int C, int DP1, bool USE_LDS>
+__device__ __forceinline__ void mf_points(const LatticeDev& L, const float* __restrict__ values, const float* tab, float alpha,
+                                          float neg_w, const ValueView& unary, int negate, const ValueView& Q, int scale_out,
+                                          const MfLabels& lab, int frame, int f0, int i0) {
+    constexpr int CP = (C + 3) / 4 * 4;
+    constexpr int PER_THREAD = MF_PTS / 256;
+    const int dp1 = DP1 > 0 ? DP1 : L.d + 1;
+    MfIn<C, DP1> cur, nxt;
+    if (i0 < L.N) mf_load<C, DP1>(L, unary, f0, (size_t)frame * L.N + i0, cur);
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {   // the staged table serves MF_PTS points
+        const int i = i0 + 256 * k;
+        if (i >= L.N) break;
+        const size_t p = (size_t)frame * L.N + i;
+        if (k + 1 < PER_THREAD && i + 256 < L.N) mf_load<C, DP1>(L, unary, f0, p + 256, nxt);   // next point's rows travel now
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < (DP1 > 0 ? DP1 : 8); j++) {
+            if (DP1 == 0 && j >= dp1) break;
+            const int o = DP1 > 0 ? cur.offs[j] : L.offsets[p * dp1 + j];
+            const float bw = DP1 > 0 ? cur.wts[j] : L.bary[p * dp1 + j];
+            float val[C];
+            if (USE_LDS) {
+                const float* row = tab + (o - f0) * CP;
+#pragma unroll
+                for (int c = 0; c < C; c++) val[c] = row[c];
+            } else {
+                load_row<C>(values + (size_t)o * C, val);
+            }
+            if (SEQ) {
+#pragma unroll
+                for (int c = 0; c < C; c++) { const float t = bw * val[c]; const float u = t * alpha; acc[c] += u; }
+            } else {
+                const float w = bw * alpha;
+#pragma unroll
+                for (int c = 0; c < C; c++) { const float prod = w * val[c]; acc[c] += prod; }
+            }
+        }
+        const float nrm = cur.nrm;
+        float b[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float t = acc[c] * nrm;
+            const float m = neg_w * t;
+            const float u = cur.ur[c];
+            b[c] = (negate ? -u : u) - m;
+        }
+        float mx = b[0];
+#pragma unroll
+        for (int c = 1; c < C; c++) if (b[c] > mx) mx = b[c];
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
+        const size_t qrow = Q.index((unsigned)p, 0, C, L.N);
+#pragma unroll
+        for (int c = 0; c < C; c++) b[c] = b[c] / sum;
+        if (lab.labels) lab.labels[((size_t)frame * lab.n_layers + lab.layer) * L.N + i] = (int8_t)label_rule(b, C, lab.mode, lab.unknown);
+        if (scale_out) {   // not the last iteration: hand the next splat its input Q * norm directly
+#pragma unroll
+            for (int c = 0; c < C; c++) b[c] = b[c] * nrm;
+        }
+        store_row<C>(Q.base + qrow, b);
+        cur = nxt;
+    }
+}
+
 template <bool SEQ, int C, int DP1>   // DP1 = d+1 at compile time (wide offset / weight loads), 0 = runtime d
 __global__ void __launch_bounds__(256)
 mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float neg_w, ValueView unary, int negate,
-                 ValueView Q, int scale_out) {
+                 ValueView Q, int scale_out, MfLabels lab) {
     extern __shared__ __attribute__((aligned(16))) float tab[];
     if (L.counters[1]) return;   // uniform: hash overflow (flagged)
     constexpr int CP = (C + 3) / 4 * 4;
@@ -1359,86 +1446,28 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     const int i0 = (blockIdx.x - frame * bpf) * MF_PTS + threadIdx.x;
     const int f0 = L.fstart[frame], f1 = L.fstart[frame + 1];
     const int Mf = f1 - f0;
-    const bool use_lds = (size_t)Mf * CP * sizeof(float) <= (size_t)MF_LDS_BYTES;
+    const bool use_lds = (size_t)Mf * CP * sizeof(float) <= (size_t)MF_LDS_BYTES;   // block-uniform
     if (use_lds) {
         for (int idx = threadIdx.x; idx < Mf * C; idx += 256) {
             const int r = idx / C, c = idx - r * C;
             tab[r * CP + c] = values[(size_t)(f0 + r) * C + c];
         }
         __syncthreads();
+        mf_points<SEQ, C, DP1, true>(L, values, tab, alpha, neg_w, unary, negate, Q, scale_out, lab, frame, f0, i0);
+    } else {
+        mf_points<SEQ, C, DP1, false>(L, values, tab, alpha, neg_w, unary, negate, Q, scale_out, lab, frame, f0, i0);
     }
-  for (int i = i0; i < i0 + MF_PTS && i < L.N; i += 256) {   // the staged table serves MF_PTS points
-    const size_t p = (size_t)frame * L.N + i;
-    const int dp1 = DP1 > 0 ? DP1 : L.d + 1;
-    float acc[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) acc[c] = 0.0f;
-    int offs[DP1 > 0 ? DP1 : 1];
-    float wts[DP1 > 0 ? DP1 : 1];
-    if (DP1 > 0) {
-        load_row<(DP1 > 0 ? DP1 : 1)>(L.offsets + p * dp1, offs);
-        load_row<(DP1 > 0 ? DP1 : 1)>(L.bary + p * dp1, wts);
-    }
-#pragma unroll
-    for (int j = 0; j < (DP1 > 0 ? DP1 : 8); j++) {
-        if (DP1 == 0 && j >= dp1) break;
-        const int o = DP1 > 0 ? offs[j] : L.offsets[p * dp1 + j];
-        const float bw = DP1 > 0 ? wts[j] : L.bary[p * dp1 + j];
-        float val[C];
-        if (use_lds) {
-            const float* row = tab + (o - f0) * CP;
-#pragma unroll
-            for (int c = 0; c < C; c++) val[c] = row[c];
-        } else {
-            load_row<C>(values + (size_t)o * C, val);
-        }
-        if (SEQ) {
-#pragma unroll
-            for (int c = 0; c < C; c++) { const float t = bw * val[c]; const float u = t * alpha; acc[c] += u; }
-        } else {
-            const float w = bw * alpha;
-#pragma unroll
-            for (int c = 0; c < C; c++) { const float prod = w * val[c]; acc[c] += prod; }
-        }
-    }
-    const float nrm = L.norm[p];
-    const size_t urow = unary.index((unsigned)p, 0, C, L.N);
-    float b[C], ur[C];
-    float mx;
-    load_row<C>(unary.base + urow, ur);
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        const float t = acc[c] * nrm;
-        const float m = neg_w * t;
-        const float u = ur[c];
-        b[c] = (negate ? -u : u) - m;
-    }
-    mx = b[0];
-#pragma unroll
-    for (int c = 1; c < C; c++) if (b[c] > mx) mx = b[c];
-    float sum = 0.0f;
-#pragma unroll
-    for (int c = 0; c < C; c++) { b[c] = exp_f32_dev(b[c] - mx); sum += b[c]; }
-    const size_t qrow = Q.index((unsigned)p, 0, C, L.N);
-#pragma unroll
-    for (int c = 0; c < C; c++) b[c] = b[c] / sum;
-    if (scale_out) {   // not the last iteration: hand the next splat its input Q * norm directly
-#pragma unroll
-        for (int c = 0; c < C; c++) b[c] = b[c] * nrm;
-    }
-    store_row<C>(Q.base + qrow, b);
-  }
 }
 
 // returns false when C has no fused instantiation (the caller then runs the unfused kernels)
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
-                      const ValueView& Q, bool scale_out, hipStream_t s) {
+                      const ValueView& Q, bool scale_out, const MfLabels& lab, hipStream_t s) {
     const float alpha = 1.0f / (1 + powf(2, (float)-L.d));
     const int bpf = (L.N + MF_PTS - 1) / MF_PTS;
     const dim3 grid((unsigned)(bpf * L.n_frames)), block(256);
 #define RV_MF(SEQ, CC)                                                                                            \
-    if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0); \
-    else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0); \
+    if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0, lab); \
+    else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0, lab); \
     return true
     switch (C) {
         case 2: RV_MF(true, 2);

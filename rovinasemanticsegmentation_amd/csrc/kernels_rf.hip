@@ -580,23 +580,7 @@ labels_kernel(const float* __restrict__ values, size_t n_points, int C, int mode
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_points) return;
     const float* v = values + i * C;
-    int best;
-    float mx;
-    if (mode == RVSEG_LABEL_EVAL) {           // test.cpp:160-175
-        best = -1; mx = -1000.f;
-        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    } else if (mode == RVSEG_LABEL_CRF) {     // segmenter.cpp:646-657
-        best = unknown; mx = (float)(2.0 / (double)C);
-        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    } else if (mode == RVSEG_LABEL_NOCRF) {   // segmenter.cpp:664-679
-        best = unknown; mx = -1000.f;
-        float sum = 0.f;
-        for (int c = 0; c < C; c++) { const float x = v[c]; sum += x; if (x > mx) { mx = x; best = c; } }
-        if (!(sum != 0.0f)) best = unknown;
-    } else {                                   // densecrf.cpp:202-211
-        best = 0; mx = v[0];
-        for (int c = 1; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    }
+    const int best = label_rule(v, C, mode, unknown);
     labels[i] = (int8_t)best;
 }
 
@@ -609,23 +593,7 @@ labels_frames_kernel(const float* __restrict__ values, int n_frames, int N, int 
     if (gid >= (size_t)n_frames * N) return;
     const size_t frame = gid / (size_t)N, i = gid - frame * (size_t)N;
     const float* v = values + frame * frame_stride + layer_off + i * C;
-    int best;
-    float mx;
-    if (mode == RVSEG_LABEL_EVAL) {
-        best = -1; mx = -1000.f;
-        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    } else if (mode == RVSEG_LABEL_CRF) {
-        best = unknown; mx = (float)(2.0 / (double)C);
-        for (int c = 0; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    } else if (mode == RVSEG_LABEL_NOCRF) {
-        best = unknown; mx = -1000.f;
-        float sum = 0.f;
-        for (int c = 0; c < C; c++) { const float x = v[c]; sum += x; if (x > mx) { mx = x; best = c; } }
-        if (!(sum != 0.0f)) best = unknown;
-    } else {
-        best = 0; mx = v[0];
-        for (int c = 1; c < C; c++) { const float x = v[c]; if (x > mx) { mx = x; best = c; } }
-    }
+    const int best = label_rule(v, C, mode, unknown);
     labels[(frame * n_layers + layer) * (size_t)N + i] = (int8_t)best;
 }
 

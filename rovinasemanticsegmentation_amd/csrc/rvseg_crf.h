@@ -103,8 +103,14 @@ float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a,
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
                   long long n_points, hipStream_t s);
 // fused slice + Potts + softmax for a single pairwise kernel; false if C is not instantiated
+// labels of the final marginals straight from the last update (the values are in registers there):
+// labels[(frame * n_layers + layer) * N + point]; labels == nullptr: none
+struct MfLabels {
+    int8_t* labels;
+    int mode, unknown, n_layers, layer;
+};
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
-                      const ValueView& Q, bool scale_out, hipStream_t s);
+                      const ValueView& Q, bool scale_out, const MfLabels& lab, hipStream_t s);
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);
 bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points,
                           const float* scale, hipStream_t s);

@@ -244,9 +244,11 @@ static void filter_into(rvseg_ctx* ctx, const LatticeBufs& b, CrfState* cs, cons
 }
 
 // DenseCRF::inference (densecrf.cpp:115-131)
+// `lab` (optional): where the last fused update may write the labels; *labels_done tells whether it did
 static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, const float* ws, const ValueView& unary,
                                bool unary_is_energy, int C, int N, long long n_points, int iterations,
-                               const ValueView& Q, hipStream_t s) {
+                               const ValueView& Q, hipStream_t s, const MfLabels* lab = nullptr, bool* labels_done = nullptr) {
+    if (labels_done) *labels_done = false;
     rvseg_status st;
     if ((st = dev_reserve(ctx, cs->tmp, (size_t)n_points * C * 4)) != RVSEG_OK) return st;
     long long mb = 0;
@@ -285,7 +287,10 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
             if (fused) {
                 timer_mark(ctx, "mf_update", s);
-                launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, it + 1 < iterations, s);
+                const bool last = it + 1 == iterations;
+                MfLabels none{nullptr, 0, 0, 0, 0};
+                launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, !last, last && lab ? *lab : none, s);
+                if (last && lab && labels_done) *labels_done = true;
                 continue;
             }
             timer_mark(ctx, "softmax", s);
@@ -346,15 +351,19 @@ rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rg
     }
     int prefix = 0;
     const float w = p.dcrf_kernel_weight;
+    bool all_labelled = true;   // the last fused update of every layer wrote its labels
     for (int l = 0; l < f.n_layers; l++) {
         const int C = f.class_counts[l];
         ValueView U{const_cast<float*>(d_post), frame_stride, (size_t)N * prefix};
         ValueView Q{marg, frame_stride, (size_t)N * prefix};
         // unary energy = -(log-posterior) (segmenter.cpp:642), so -U is the posterior itself
-        if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, s)) != RVSEG_OK) return st;
+        MfLabels lab{d_labels, p.label_mode, p.unknown_label[l], f.n_layers, l};
+        bool done = false;
+        if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, s, d_labels ? &lab : nullptr, &done)) != RVSEG_OK) return st;
+        all_labelled = all_labelled && done;
         prefix += C;
     }
-    if (d_labels) {
+    if (d_labels && !all_labelled) {
         timer_mark(ctx, "labels", s);
         launch_labels_frames(marg, n, N, f, p.label_mode, p.unknown_label, d_labels, s);
     }
