@@ -46,7 +46,7 @@ PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.m
 
 # stage name -> kernel whose PMC counters (profiles/*_pmc_batch64.json, collected with separate
 # rocprofv3 --pmc passes of this very command) give the HBM traffic per launch
-STAGE_KERNEL = {"splat": "rvseg::splat_gather_kernel<0, 9, false>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
+STAGE_KERNEL = {"splat": "rvseg::splat_group_kernel<0, 9, true>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
                 "rf_frames": "rvseg::rf_frames_kernel<false>"}
 
 

@@ -635,56 +635,6 @@ csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     }
 }
 
-// Range-major variant of the scan.  The frame is cut into ranges of L.range_wb wave-blocks; the
-// csr arrays are ordered (range, vertex, point), so that a vertex's entries inside one range (a
-// "piece") are contiguous.  The ordered splat then advances range by range (one launch per range):
-// all readers of a range's Q rows run together and share them in L2, and a vertex's running sum
-// is carried from piece to piece through `values`.  Every range holds exactly
-// range_wb * CS_PIX * (d+1) entries, so range bases are known without a scan.
-// One wave owns the ranges r = wave, wave+16, ...; no block-level synchronisation is needed.
-__global__ void __launch_bounds__(1024)
-csr_scan_range_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
-    const int frame = blockIdx.x;
-    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
-    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
-    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
-    const int lvl = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned* fb = bh + (size_t)wbpf * f0;
-    const int grp = frame % L.n_groups;
-    const unsigned frame_base = (unsigned)((long long)frame * L.N * (L.d + 1));
-    const unsigned range_entries = (unsigned)L.range_wb * CS_PIX * (unsigned)(L.d + 1);
-    for (int r = wave; r < L.n_ranges; r += 16) {
-        const int w0 = r * L.range_wb, w1 = (w0 + L.range_wb < wbpf) ? w0 + L.range_wb : wbpf;
-        unsigned carry = 0;   // entries of the range taken by vertices below the current chunk
-        for (int lv0 = 0; lv0 < Mf; lv0 += 64) {
-            const int lv = lv0 + lvl;
-            const bool ok = lv < Mf;
-            unsigned cnt = 0;
-            if (ok) for (int w = w0; w < w1; w++) cnt += fb[(size_t)w * Mf + lv];
-            unsigned incl = cnt;
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = __shfl_up(incl, off, 64);
-                if (lvl >= off) incl += t;
-            }
-            const unsigned start = frame_base + (unsigned)r * range_entries + carry + incl - cnt;
-            if (ok) {
-                if (cnt > 0) {   // non-empty piece: append to the (range, frame group) work list
-                    const unsigned li = (unsigned)(r * L.n_groups + grp);
-                    const unsigned slot = atomicAdd(L.pcount + li, 1u);
-                    if (slot < L.pcap) L.plist[(size_t)li * L.pcap + slot] = make_uint4((unsigned)(f0 + lv), start, cnt, 0u);
-                }
-                unsigned run = start;
-                for (int w = w0; w < w1; w++) {
-                    const unsigned t = fb[(size_t)w * Mf + lv];
-                    fb[(size_t)w * Mf + lv] = run;
-                    run += t;
-                }
-            }
-            carry += __shfl(incl, 63, 64);
-        }
-    }
-}
-
 bool csr_fast_path(const LatticeDev& L) { return ((L.cap_f_mask + 1) / 2) <= (unsigned)CS_MCAP; }
 size_t csr_fast_bytes(const LatticeDev& L) {
     const size_t wbpf = ((size_t)L.N + CS_PIX - 1) / CS_PIX;
@@ -708,8 +658,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
         csr_pass_kernel<false><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        if (L.range_mode) csr_scan_range_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
-        else csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
+        csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
         if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
@@ -722,7 +671,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
                                         (unsigned)sb.key_bits, s);
         lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
     }
-    if (!L.range_mode) launch_vertex_order(L, sb, s);
+    launch_vertex_order(L, sb, s);
 }
 
 // Launch order of the vertices for the splat: grouped by (frame mod G) so that, with the
@@ -730,7 +679,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
 // the same XCD and shares its L2 (speed only, never correctness); inside a group longest list
 // first (LPT: the serial chains of the heaviest vertices start at t = 0).
 __global__ void __launch_bounds__(256)
-vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids, int frame_major) {
+vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.m_bound) return;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
@@ -740,10 +689,6 @@ vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict
         const unsigned frame = (unsigned)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
         const unsigned g = frame % (unsigned)L.n_groups;
         k = (g << 28) | (0x0FFFFFFFu - (len < 0x0FFFFFFFu ? len : 0x0FFFFFFFu));
-        if (frame_major) {
-            const unsigned fr = frame / (unsigned)L.n_groups, l16 = len >> 4;
-            k = (g << 28) | ((fr < 255u ? fr : 255u) << 20) | (0xFFFFFu - (l16 < 0xFFFFFu ? l16 : 0xFFFFFu));
-        }
     }
     key[v] = k;
     ids[v] = (unsigned)v;
@@ -765,8 +710,7 @@ group_count_kernel(LatticeDev L) {
 
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
     group_count_kernel<<<dim3(1), dim3(64), 0, s>>>(L);
-    static const int frame_major = getenv("RVSEG_SPLAT_FRAME_MAJOR") ? atoi(getenv("RVSEG_SPLAT_FRAME_MAJOR")) : 0;
-    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, frame_major);
+    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in);
     size_t temp = sb.temp_bytes;
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
 }
@@ -803,130 +747,15 @@ void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
 // splat as an ordered gather: one lane per (vertex, class) chain.
 //   values[v][c] = sum over the vertex's entries, ascending point index, of fl(w * in[p][c])
 //   with in[p][c] = fl(Q[p][c] * norm[p]) when `scaled` (DenseKernel::filter, pairwise.cpp:66)
+// Per tile of 64 list entries the lanes of a producer wave form the 64 x C products in parallel
+// (coalesced reads of the CSR pairs, one gathered Q row per lane) and park them in LDS; a lane
+// (vertex, class) of the adder wave then adds the tile's products in list order -- the only part
+// that has to be sequential.
+// MODE 0: in = src[p*C+c]; 1: in = fl(src*norm) (per-entry normaliser csr_nrm); 2: in = 1 (normaliser pass).
+// CC = classes handled by a pass (compile time, so the body is branch-free and the compiler keeps
+// counted vmcnt waits); classes [c0, c0 + n_store) are stored, n_store <= CC.
 // ---------------------------------------------------------------------------------------------
-// One wavefront per vertex.  Per tile of 64 list entries the lanes first form the 64 x C products
-// in parallel (coalesced reads of the CSR arrays, one gathered Q row per lane) and park them in
-// LDS; then lane c adds the tile's products of class c in list order -- the only part that has to
-// be sequential.  The next tile's loads are issued before the sequential phase so that their
-// latency hides behind the dependent adds.
-constexpr int SPLAT_R = 4;    // register ring: entries are loaded 3 tiles ahead, Q rows gathered 2 ahead
-
-// CC = classes handled by this pass (compile time, so the body is branch-free and the compiler
-// keeps counted vmcnt waits); classes [c0, c0 + n_store) are stored, n_store <= CC; lanes of the
-// padding classes re-read class c0 + n_store - 1 and drop the result.
-// RANGE = false: one launch, a block sums a vertex's whole list.
-// RANGE = true : launch `range` of n_ranges; a block sums the vertex's piece inside that range and
-//                carries the running sum in `values` (zeroed by the caller before range 0).
-template <int MODE, int CC, bool RANGE>  // MODE 0: in = src[p*C+c]; 1: in = fl(src*norm); 2: in = 1 (normaliser)
-__global__ void __launch_bounds__(64)
-splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int range) {
-    __shared__ __attribute__((aligned(16))) float prod[CC][68];  // 16-B aligned rows, 4-bank skew
-    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
-    const int lane = threadIdx.x;
-    // block b -> group b % G (= the XCD it lands on when G == 8), rank b / G inside the group
-    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j0 = blockIdx.x / (unsigned)L.n_groups;
-    const unsigned jstep = gridDim.x / (unsigned)L.n_groups;
-    unsigned n_items, gstart = 0;
-    if (RANGE) {
-        n_items = L.pcount[range * L.n_groups + g];
-        n_items = n_items < L.pcap ? n_items : L.pcap;
-    } else {
-        n_items = L.gcount[g];
-        for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
-    }
-  for (unsigned j = j0; j < n_items; j += jstep) {   // RANGE: a block may own several pieces of this range
-    int v;
-    unsigned k0, k1;
-    if (RANGE) {
-        const uint4 pc = L.plist[(size_t)(range * L.n_groups + g) * L.pcap + j];
-        v = (int)pc.x; k0 = pc.y; k1 = pc.y + pc.z;
-    } else {
-        v = (int)L.vorder[gstart + j];
-        k0 = L.vstart[v]; k1 = L.vend[v];
-    }
-    const unsigned n_tiles = (k1 - k0 + 63u) / 64u;
-    if (n_tiles == 0) {  // vertex created by a padding lane only: no mass
-        if (lane < n_store) values[(size_t)v * C + c0 + lane] = 0.0f;
-        continue;
-    }
-    float acc = 0.0f;
-    if (RANGE && lane < n_store) acc = values[(size_t)v * C + c0 + lane];   // carry from the earlier ranges
-    float x[SPLAT_R][CC];
-    float w[SPLAT_R], nrm[SPLAT_R];
-    unsigned pix[SPLAT_R];
-#pragma unroll
-    for (int r = 0; r < SPLAT_R; r++) { w[r] = 0.f; nrm[r] = 1.f; pix[r] = 0u; }
-
-    // Loads are unconditional (indices clamped into the vertex's list) so that no divergent branch
-    // forces the compiler to drain the memory queue.
-    auto load_entries = [&](unsigned tile, int slot) {
-        unsigned k = k0 + tile * 64u + lane;
-        k = k < k1 ? k : k1 - 1u;
-        const uint2 pw = L.csr_pw[k];     // {point, weight} in one 8-byte load
-        w[slot] = __uint_as_float(pw.y);
-        pix[slot] = pw.x;
-        if (MODE == 1) nrm[slot] = L.csr_nrm[k];
-    };
-    auto gather_rows = [&](int slot) {
-        if (MODE == 2) return;
-        const size_t row = src.index(pix[slot], c0, C, L.N);
-        if (n_store == CC) {
-            load_row<CC>(src.base + row, x[slot]);   // ceil(CC/4) wide requests per lane
-        } else {
-#pragma unroll
-            for (int c = 0; c < CC; c++) x[slot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
-        }
-    };
-    // prologue: entries of tiles 0..2, rows of tiles 0..1
-    load_entries(0, 0); load_entries(1, 1); load_entries(2, 2);
-    gather_rows(0); gather_rows(1);
-
-    bool more = true;
-    for (unsigned t0 = 0; more; t0 += SPLAT_R) {
-#pragma unroll
-        for (int s = 0; s < SPLAT_R; s++) {
-            const unsigned t = t0 + s;
-            // `break`, not `if`: a later stage must never be reachable past a skipped earlier one, or
-            // the compiler has to assume that path and drains the load queue (vmcnt(0)) in every stage
-            if (t >= n_tiles) { more = false; break; }
-            {
-                const unsigned base = k0 + t * 64u;
-                const unsigned n_valid = k1 - base < 64u ? k1 - base : 64u;
-                // lanes beyond the list park +0.0f: the running sum starts at +0 and can never become -0,
-                // so adding +0 is the identity and every tile can run the same 64 adds (no tail branch)
-                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < CC; c++) {
-                    float xin = MODE == 2 ? 1.0f : x[s][c];
-                    if (MODE == 1) xin = xin * nrm[s];
-                    const float pr = wl * xin;
-                    prod[c][lane] = (unsigned)lane < n_valid ? pr : 0.0f;
-                }
-                __syncthreads();
-                // keep the memory pipeline full while the dependent adds below run
-                load_entries(t + 3, (s + 3) % SPLAT_R);
-                gather_rows((s + 2) % SPLAT_R);
-                {
-                    // all 16 quad reads are issued before the first add: one LDS round trip per tile;
-                    // the adds stay strictly in list order.  Lanes >= CC compute on row 0 and are ignored
-                    // (no divergent branch, so the memory waits stay counted).
-                    const float* pr = prod[lane < CC ? lane : 0];
-                    float4 q[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
-                }
-                __syncthreads();
-            }
-        }
-    }
-    if (lane < n_store) values[(size_t)v * C + c0 + lane] = acc;
-  }
-}
-
-
-// Grouped form of the same sum (the default).  PMC on the one-wave-per-vertex kernel above showed it
+// The first version ran one wave per vertex (products and adds in the same wave).  PMC showed it
 // issue bound: of ~150 instructions per 64-entry tile, 64 adds + 16 LDS reads run with only C of 64
 // lanes busy.  Here a block owns G = 64 / CC vertices of similar list length (neighbours in
 // `vorder`): wave i < G forms the products of vertex i's tile t exactly as above, and ONE extra
@@ -936,7 +765,7 @@ splat_gather_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, flo
 template <int CC> struct SplatGroup { static constexpr int G = 64 / CC > 8 ? 8 : 64 / CC; };
 // A vertex's chain advances one tile per barrier, so the loads of a tile have to be in flight for
 // many tiles: {point, weight} pairs are fetched SPLAT_RE - 1 tiles ahead and the Q rows they point at
-// SPLAT_RR - 1 tiles ahead (the one-wave kernel above keeps 3 / 2 and stalls a memory round trip per tile).
+// SPLAT_RR - 1 tiles ahead (a ring of 3 / 2 tiles stalled a memory round trip per tile).
 constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is written out for RE == 16
 
 template <int MODE, int CC, bool FULL>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
@@ -1088,47 +917,7 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
     else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
 }
 
-template <int MODE, bool RANGE>
-static void splat_pass(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, int range, hipStream_t s) {
-    const dim3 grid(RANGE ? L.range_grid : L.splat_grid), block(64);
-    if (n == 1) splat_gather_kernel<MODE, 1, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-    else if (n == 2) splat_gather_kernel<MODE, 2, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-    else if (n <= 4) splat_gather_kernel<MODE, 4, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-    else if (n <= 8) splat_gather_kernel<MODE, 8, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-    else if (n == 9) splat_gather_kernel<MODE, 9, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-    else splat_gather_kernel<MODE, 16, RANGE><<<grid, block, 0, s>>>(L, src, C, c0, n, values, range);
-}
-
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
-    if (L.range_mode) {
-        // running sums start at zero; vertices without entries keep it
-        (void)hipMemsetAsync(values, 0, (size_t)L.m_bound * (mode == 2 ? 1 : C) * sizeof(float), s);
-        for (int r = 0; r < L.n_ranges; r++) {
-            if (mode == 2) {
-                splat_gather_kernel<2, 1, true><<<dim3(L.range_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, r);
-                continue;
-            }
-            for (int c0 = 0; c0 < C; c0 += 16) {
-                const int n = C - c0 < 16 ? C - c0 : 16;
-                if (mode == 0) splat_pass<0, true>(L, src, C, c0, n, values, r, s);
-                else splat_pass<1, true>(L, src, C, c0, n, values, r, s);
-            }
-        }
-        return;
-    }
-    static const bool wave_per_vertex = getenv("RVSEG_SPLAT_WAVE") && atoi(getenv("RVSEG_SPLAT_WAVE")) != 0;
-    if (wave_per_vertex) {   // the earlier kernel, kept for A/B timing
-        if (mode == 2) {
-            splat_gather_kernel<2, 1, false><<<dim3((unsigned)L.splat_grid), dim3(64), 0, s>>>(L, src, 1, 0, 1, values, 0);
-            return;
-        }
-        for (int c0 = 0; c0 < C; c0 += 16) {
-            const int n = C - c0 < 16 ? C - c0 : 16;
-            if (mode == 0) splat_pass<0, false>(L, src, C, c0, n, values, 0, s);
-            else splat_pass<1, false>(L, src, C, c0, n, values, 0, s);
-        }
-        return;
-    }
     if (mode == 2) {
         splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;

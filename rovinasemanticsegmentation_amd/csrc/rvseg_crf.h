@@ -36,14 +36,6 @@ struct LatticeDev {
     unsigned* gcount;            // vertices per group (8 counters)
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
     unsigned splat_grid;         // n_groups * (largest possible group)
-    // range mode (large frames on the counting-sort path): csr order (range, vertex, point)
-    int range_mode;              // 1: splat advances range by range, carrying sums in `values`
-    int range_wb;                // wave-blocks (of CS_PIX points) per range
-    int n_ranges;
-    unsigned range_grid;         // blocks per range launch
-    uint4* plist;                // per (range, frame group): non-empty pieces {vertex, start, length, -}
-    unsigned* pcount;            // per (range, frame group): number of pieces
-    unsigned pcap;               // capacity of one piece list
     // banded splat (counting-sort path): after the scan, bh[wave-block][vertex] is the position of the
     // vertex's first entry at or after that wave-block, i.e. the vertex-major lists can be cut at any
     // multiple of CS_PIX points without another sort

@@ -13,7 +13,7 @@ namespace rvseg {
 
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pw, csr_nrm, vstart, vend, norm;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount, block_hist, plist, pcount;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount, block_hist;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -41,7 +41,7 @@ static CrfState* crf_state(Pipeline* im) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount, &b.block_hist, &b.plist, &b.pcount};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount, &b.block_hist};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -141,7 +141,6 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
     b.sb.scan_temp = b.scan_temp.p; b.sb.scan_temp_bytes = stemp;
     b.sb.block_hist = nullptr;
-    L.range_mode = 0; L.range_wb = 0; L.n_ranges = 0; L.range_grid = 0; L.plist = nullptr; L.pcount = nullptr; L.pcap = 0;
     L.bh = nullptr; L.wbpf = 0; L.n_bands = 1; L.band_wb = 0;
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
@@ -155,29 +154,6 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
             nb = nb < 1 ? 1 : (nb > L.wbpf ? L.wbpf : nb);
             L.band_wb = (L.wbpf + nb - 1) / nb;
             L.n_bands = (L.wbpf + L.band_wb - 1) / L.band_wb;
-        }
-        // Large frames: order the entries (range, vertex, point) and splat range by range, so that the
-        // d+1 readers of a Q row run at the same time and share it in L2.
-        const char* env = std::getenv("RVSEG_SPLAT_RANGE");
-        const int pix = csr_pix_per_block();
-        const int wbpf = (N + pix - 1) / pix;
-        // Measured on MI355X (batch 64, 640x480, C = 9): range mode 8.4 ms vs 6.8 ms per step for the
-        // single-launch vertex-major splat -- the splat is bound by vector-memory request issue and
-        // the serial adds, not by HBM traffic -- so it stays opt-in (RVSEG_SPLAT_RANGE=1).
-        if (N >= 65536 && env && env[0] == '1') {
-            int range_wb = 32;                                  // 8192 points per range
-            while ((wbpf + range_wb - 1) / range_wb > 64) range_wb *= 2;
-            L.range_mode = 1;
-            L.range_wb = range_wb;
-            L.n_ranges = (wbpf + range_wb - 1) / range_wb;
-            const unsigned long long frames_per_group = ((unsigned long long)n_frames + L.n_groups - 1) / L.n_groups;
-            L.pcap = (unsigned)std::min<unsigned long long>(frames_per_group * ((1ull << cap_f_log2) / 2), m_bound);
-            // one block per piece in the common case (~100 non-empty pieces per frame and range)
-            L.range_grid = (unsigned)(L.n_groups * std::min<unsigned long long>(L.pcap, 1024));
-            if ((st = dev_reserve(ctx, b.plist, (size_t)L.n_ranges * L.n_groups * L.pcap * sizeof(uint4))) != RVSEG_OK) return st;
-            if ((st = dev_reserve(ctx, b.pcount, (size_t)L.n_ranges * L.n_groups * 4)) != RVSEG_OK) return st;
-            L.plist = b.plist.as<uint4>();
-            L.pcount = b.pcount.as<unsigned>();
         }
     }
     b.n_entries = E; b.n_points = P;
@@ -199,7 +175,6 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
     RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
     RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
-    if (L.range_mode) RV_HIP(ctx, hipMemsetAsync(L.pcount, 0, (size_t)L.n_ranges * L.n_groups * 4, s));
     const bool trace = std::getenv("RVSEG_TRACE") != nullptr;
     auto tr = [&](const char* what) {
         if (!trace) return;

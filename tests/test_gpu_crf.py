@@ -135,20 +135,21 @@ def test_frames_with_crf_bit_exact(gpu_ctx_factory, oracle):
     assert np.allclose(m.sum(1), 1, atol=1e-5)
 
 
-def test_range_major_splat_is_bit_exact_too(gpu_ctx_factory, oracle):
-    """RVSEG_SPLAT_RANGE=1 orders the entries (range, vertex, point) and carries the running sums
-    from range to range; the additions per vertex stay in point order, so nothing may change."""
+def test_banded_splat_is_bit_exact_too(gpu_ctx_factory, oracle):
+    """RVSEG_SPLAT_BANDS=n cuts every vertex list at n - 1 pixel boundaries and sums band after band
+    (one launch each), carrying the running sums in memory; the additions per vertex stay in point
+    order, so nothing may change.  (Timing experiment of DESIGN.md, section 4.)"""
     blob = synthetic.make_forest_bytes(seed=22, n_trees=3, leaves_per_tree=256, max_depth=12)
     forest = oracle.Forest(blob)
     rgb, depth = synthetic.make_batch(1, holes=True, start=5)
     calib = synthetic.make_calib()
-    os.environ["RVSEG_SPLAT_RANGE"] = "1"
+    os.environ["RVSEG_SPLAT_BANDS"] = "5"
     try:
         ctx = gpu_ctx_factory(use_dense_crf=1, dcrf_iterations=2, label_mode=3)
         ctx.forest_load(blob)
         out = ctx.segment_frames(rgb, depth, calib)
     finally:
-        del os.environ["RVSEG_SPLAT_RANGE"]
+        del os.environ["RVSEG_SPLAT_BANDS"]
     p = oracle.default_params(dcrf_iterations=2)
     post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[0], depth[0], calib, label_mode=3)
     assert np.array_equal(out["marginals"][0], marg)
