@@ -805,10 +805,10 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
                 if (i == wave) { my_k0 = k0; my_k1 = k1; }
             }
         }
-        // the launch lasts as long as its longest chains: their waves win issue arbitration on a shared SIMD
-        if (n_steps > 512u) __builtin_amdgcn_s_setprio(3);
-        else if (n_steps > 128u) __builtin_amdgcn_s_setprio(2);
-        else if (n_steps > 32u) __builtin_amdgcn_s_setprio(1);
+        // the adder's 64 dependent adds are the critical path of every step: it wins issue arbitration
+        // against the producers (which run a tile ahead and have slack)
+        if (wave == G) __builtin_amdgcn_s_setprio(3);
+        else if (n_steps > 256u) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         if (wave < G) {
             // ---- producer of vertex `wave`: barriers 0 .. n_steps - 1 close its tiles, one more ends the item
