@@ -16,6 +16,7 @@
 //   * The reference splats sequentially over points, so a vertex's fp32 sum is ordered by point
 //     index.  To stay bit-exact the splat is a GATHER: entries are stably sorted by vertex and each
 //     (vertex, class) chain adds its contributions in ascending point order.  No float atomics.
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 #include <string.h>
@@ -674,43 +675,30 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     launch_vertex_order(L, sb, s);
 }
 
-// Launch order of the vertices for the splat: grouped by (frame mod G) so that, with the
-// dispatcher dealing blocks round-robin over the 8 XCDs, every reader of a frame's Q rows runs on
-// the same XCD and shares its L2 (speed only, never correctness); inside a group longest list
-// first (LPT: the serial chains of the heaviest vertices start at t = 0).
+// Launch order of the vertices for the splat: per frame, longest list first.  vorder[fstart[f] + k]
+// is the k-th longest vertex of frame f (ids are frame-contiguous, so a sort by (frame, -length)
+// keeps every frame in its own id range).  The splat forms its groups of G vertices inside a frame
+// and starts all frames' heaviest groups first (LPT: the serial chains of the heaviest vertices
+// start at t = 0).
 __global__ void __launch_bounds__(256)
-vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids) {
+vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict__ ids, int len_shift) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= L.m_bound) return;
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
     unsigned k = 0xFFFFFFFFu;  // unused ids sort to the end
     if (v < M) {
-        const unsigned len = L.vend[v] - L.vstart[v];
+        const unsigned len = (L.vend[v] - L.vstart[v]) >> len_shift;
         const unsigned frame = (unsigned)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
-        const unsigned g = frame % (unsigned)L.n_groups;
-        k = (g << 28) | (0x0FFFFFFFu - (len < 0x0FFFFFFFu ? len : 0x0FFFFFFFu));
+        k = ((frame < 1023u ? frame : 1022u) << 22) | (0x3FFFFFu - (len < 0x3FFFFFu ? len : 0x3FFFFFu));
     }
     key[v] = k;
     ids[v] = (unsigned)v;
 }
 
-// vertices per launch group = the vertices of its frames (ids are frame-contiguous)
-__global__ void __launch_bounds__(64)
-group_count_kernel(LatticeDev L) {
-    const int g = threadIdx.x;
-    if (g >= L.n_groups) return;
-    const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
-    unsigned n = 0;
-    for (int f = g; f < L.n_frames; f += L.n_groups) {
-        const int a = L.fstart[f] < M ? L.fstart[f] : M, b = L.fstart[f + 1] < M ? L.fstart[f + 1] : M;
-        n += (unsigned)(b - a);
-    }
-    L.gcount[g] = n;
-}
-
 void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
-    group_count_kernel<<<dim3(1), dim3(64), 0, s>>>(L);
-    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in);
+    int len_shift = 0;   // a list has at most N entries
+    while (((long long)L.N >> len_shift) >= (1 << 22)) len_shift++;
+    vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, len_shift);
     size_t temp = sb.temp_bytes;
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
 }
@@ -776,19 +764,25 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // block b -> group b % n_groups (= the XCD it lands on when n_groups == 8), rank b / n_groups inside it
-    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j0 = blockIdx.x / (unsigned)L.n_groups;
-    const unsigned jstep = gridDim.x / (unsigned)L.n_groups;
-    const unsigned n_vert = L.gcount[g];
-    unsigned gstart = 0;
-    for (unsigned q = 0; q < g; q++) gstart += L.gcount[q];
-    const unsigned n_items = (n_vert + G - 1) / G;
+    // block b -> XCD group b % n_groups (the dispatcher deals blocks round-robin over the 8 XCDs), item
+    // b / n_groups inside it.  A group owns the frames f = g, g + n_groups, ...: all readers of a
+    // frame's Q rows share one L2.  Item j = (rank r, frame slot q): the r-th heaviest G vertices of
+    // that frame -- every frame's heaviest vertices are dispatched first.
+    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j = blockIdx.x / (unsigned)L.n_groups;
+    const unsigned nfg = ((unsigned)L.n_frames - g + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;   // frames of this group
+    if (nfg == 0) return;
+    const unsigned r = j / nfg, frame = g + (j - r * nfg) * (unsigned)L.n_groups;
+    const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int fs0 = L.fstart[frame] < Mtot ? L.fstart[frame] : Mtot;
+    const int fs1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
+    const unsigned n_vert = (unsigned)(fs1 - fs0), gstart = (unsigned)fs0;
+    if (r * G >= n_vert) return;
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
-    for (unsigned j = j0; j < n_items; j += jstep) {
+    {
         // every wave reads the group's G list ranges itself (uniform): no broadcast step
         unsigned n_steps = 0, my_k0 = 0, my_k1 = 0;
         for (int i = 0; i < G; i++) {
-            const unsigned idx = j * G + i;
+            const unsigned idx = r * G + i;
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
                 unsigned k0 = L.vstart[v], k1 = L.vend[v];
@@ -876,7 +870,7 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
         } else {
             // ---- adder: lane (i, c) owns the chain of vertex i, class c
             const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
-            const unsigned idx = j * G + gi;
+            const unsigned idx = r * G + gi;
             const bool mine = lane < G * CC && idx < n_vert && c < n_store;
             const unsigned cv = mine ? L.vorder[gstart + idx] : 0u;
             float acc = 0.0f;
@@ -899,7 +893,10 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
 template <int MODE, int CC>
 static void splat_group_launch(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
     constexpr int G = SplatGroup<CC>::G;
-    const unsigned per_group = (L.splat_grid / (unsigned)L.n_groups + G - 1) / G;
+    // items per XCD group: (frames of the group) x (groups of G vertices a frame can have at most)
+    const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
+    const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
+    const unsigned per_group = nfg * (unsigned)((max_mf + G - 1) / G);
     const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
     for (int band = 0; band < L.n_bands; band++) {
         if (n == CC) splat_group_kernel<MODE, CC, true><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);

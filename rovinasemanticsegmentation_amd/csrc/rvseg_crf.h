@@ -32,10 +32,8 @@ struct LatticeDev {
                                  // {point index, barycentric weight bits}
     float* csr_nrm;              // norm[point] per entry (multi-kernel path only, built on demand)
     unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
-    unsigned* vorder;            // vertex ids in splat launch order (grouped by frame mod n_groups, longest first)
-    unsigned* gcount;            // vertices per group (8 counters)
+    unsigned* vorder;            // vorder[fstart[f] + k] = k-th longest vertex of frame f (splat launch order)
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
-    unsigned splat_grid;         // n_groups * (largest possible group)
     // banded splat (counting-sort path): after the scan, bh[wave-block][vertex] is the position of the
     // vertex's first entry at or after that wave-block, i.e. the vertex-major lists can be cut at any
     // multiple of CS_PIX points without another sort

@@ -13,7 +13,7 @@ namespace rvseg {
 
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pw, csr_nrm, vstart, vend, norm;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, gcount, block_hist;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, block_hist;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -41,7 +41,7 @@ static CrfState* crf_state(Pipeline* im) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.gcount, &b.block_hist};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -100,7 +100,6 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.vstart, m_bound * 4);
     RV_RES(b.vend, m_bound * 4);
     RV_RES(b.vorder, m_bound * 4);
-    RV_RES(b.gcount, 64);
     RV_RES(b.norm, P * 4);
     const unsigned long long SE = std::max<unsigned long long>((unsigned long long)E, m_bound);  // also sorts the vertex order
     RV_RES(b.keys_in, SE * 4);
@@ -129,13 +128,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.csr_pw = b.csr_pw.as<uint2>(); L.csr_nrm = nullptr;
     b.has_csr_nrm = false;
     L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.vorder = b.vorder.as<unsigned>(); L.norm = b.norm.as<float>();
-    L.gcount = b.gcount.as<unsigned>();
     L.n_groups = n_frames >= 8 ? 8 : 1;
-    {
-        const unsigned long long frames_per_group = ((unsigned long long)n_frames + L.n_groups - 1) / L.n_groups;
-        const unsigned long long per_group = std::min<unsigned long long>(frames_per_group * ((cap >> cap_f_log2 ? (1ull << cap_f_log2) : 0) / 2 + 1) + 2, m_bound);
-        L.splat_grid = (unsigned)(per_group * L.n_groups);
-    }
     b.sb.keys_in = b.keys_in.as<unsigned>(); b.sb.keys_out = b.keys_out.as<unsigned>();
     b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
