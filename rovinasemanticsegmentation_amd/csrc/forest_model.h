@@ -20,7 +20,8 @@ struct DeviceNode {
     int32_t feature;   // split feature index (inner nodes)
     float threshold;   // go left iff x[feature] < threshold  (classifier.cpp:105)
     int32_t left;      // absolute index of the left child in the node array; 0 <=> leaf
-    int32_t leaf_row;  // row of the leaf in the histogram tables (leaves only)
+    int32_t leaf_row;  // leaves: row in the histogram tables; inner nodes on the device: packed patch
+                       // coordinates of `feature` (channel << 16 | dy << 8 | dx), see upload_forest
 };
 
 struct ForestModel {

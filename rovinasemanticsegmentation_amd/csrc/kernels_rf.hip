@@ -341,9 +341,8 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
 
     // one value of the r x r x 3 patch vector: cv::resize(ROI -> r x r) in 11-bit fixed point
     // (feature_extractor.h:142), exactly phase B of the kernel above for cell k, channel c
-    auto patch_value = [&](int f) -> float {
-        const int k = f / 3, c = f - 3 * k;
-        const int dy = k / g.r, dx = k - dy * g.r;
+    auto patch_value = [&](int packed) -> float {   // packed = channel << 16 | dy << 8 | dx (upload_forest)
+        const int c = packed >> 16, dy = (packed >> 8) & 255, dx = packed & 255;
         const uint2 xr = *reinterpret_cast<const uint2*>(&myrt->x[dx]);
         const uint2 yr = *reinterpret_cast<const uint2*>(&myrt->y[dy]);
         const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
@@ -381,7 +380,7 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
                 const int4 c0 = np[nd.z], c1 = np[nd.z + 1];
                 const int f = nd.x;
                 float v;
-                if (f < g.n_patch) v = patch_value(f);
+                if (f < g.n_patch) v = patch_value(nd.w);
                 else v = f == g.pos_depth ? depth_m : (f == g.pos_height ? height : nrm);
                 nd = (v < __int_as_float(nd.y)) ? c0 : c1;
             }

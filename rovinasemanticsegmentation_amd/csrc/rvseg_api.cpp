@@ -106,7 +106,24 @@ static rvseg_status upload_forest(rvseg_ctx* ctx) {
     if ((st = dev_alloc(ctx, f.nodes, m.nodes.size() * sizeof(DeviceNode))) != RVSEG_OK) return st;
     if ((st = dev_alloc(ctx, f.roots, m.roots.size() * sizeof(int32_t))) != RVSEG_OK) return st;
     if ((st = dev_alloc(ctx, f.hist, hist.size() * sizeof(float))) != RVSEG_OK) return st;
-    RV_HIP(ctx, hipMemcpy(f.nodes.p, m.nodes.data(), m.nodes.size() * sizeof(DeviceNode), hipMemcpyHostToDevice));
+    {
+        // inner nodes do not use `leaf_row`: park the patch coordinates of the tested feature there
+        // (feature f of the r x r x 3 patch = cell (dy, dx), channel c; feature_extractor.h:160-167), so the
+        // frame kernel needs no divisions per visited node
+        std::vector<DeviceNode> nodes = m.nodes;
+        const int r = ctx->params.patch_size_reduce;
+        const int n_patch = ctx->params.feature_color_patch ? r * r * 3 : 0;
+        for (DeviceNode& dn : nodes) {
+            if (dn.left == 0) continue;
+            dn.leaf_row = 0;
+            if (dn.feature < n_patch) {
+                const int k = dn.feature / 3, c = dn.feature - 3 * k;
+                const int dy = k / r, dx = k - dy * r;
+                dn.leaf_row = (c << 16) | (dy << 8) | dx;
+            }
+        }
+        RV_HIP(ctx, hipMemcpy(f.nodes.p, nodes.data(), nodes.size() * sizeof(DeviceNode), hipMemcpyHostToDevice));
+    }
     RV_HIP(ctx, hipMemcpy(f.roots.p, m.roots.data(), m.roots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RV_HIP(ctx, hipMemcpy(f.hist.p, hist.data(), hist.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->forest_loaded = true;
