@@ -172,3 +172,39 @@ def test_config5_shape_dual_layer_10_iterations(gpu_ctx_factory, oracle):
     assert np.abs(out["marginals"][0] - marg).max() <= TOL
     assert np.array_equal(out["marginals"][0], marg)
     assert np.array_equal(out["labels"][0].ravel(), lab)
+
+
+@pytest.mark.parametrize("C,d", [(11, 6), (17, 4), (1, 2)])
+def test_crf_infer_class_counts_without_a_fused_update(gpu_ctx_factory, oracle, C, d):
+    """C = 11: no fused slice+softmax instantiation (per-entry normaliser, separate kernels);
+    C = 17: two splat passes (16 + 1 classes, the second with a partial row); C = 1: degenerate."""
+    rng = np.random.default_rng(100 + C)
+    N = 6000
+    F = _features(7, N, d, spread=3.0)
+    U = (rng.random((N, C)) * 4).astype(np.float32)
+    want = oracle.crf_inference(U, F, 3.0, 3)
+    ctx = gpu_ctx_factory()
+    Q, mp = ctx.crf_infer(U, F, 3.0, 3)
+    assert np.abs(Q - want).max() <= TOL
+    assert np.array_equal(Q, want)
+    assert np.array_equal(mp, oracle.labels(want, C, 3))
+
+
+def test_ten_small_frames_uneven_xcd_groups(gpu_ctx_factory, oracle):
+    """10 frames in one chunk: 8 launch groups with 2, 2, 1, ... frames each, 6 trees (not a multiple of
+    the 4 tree lanes per point), dual layer, fused labels."""
+    W, H = 160, 120
+    blob = synthetic.make_forest_bytes(seed=31, n_trees=6, leaves_per_tree=256, max_depth=14)
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(10, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, use_dense_crf=1, dcrf_iterations=2, label_mode=1, max_batch=16, unknown_label=[7, 8])
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    p = oracle.default_params(width=W, height=H, dcrf_iterations=2)
+    for i in range(10):
+        post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[7, 8])
+        assert np.array_equal(out["posteriors"][i], post), i
+        assert np.array_equal(out["marginals"][i], marg), i
+        assert np.array_equal(out["labels"][i].ravel(), lab), i

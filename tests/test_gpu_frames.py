@@ -137,3 +137,20 @@ def test_frame_without_any_valid_depth(gpu_ctx_factory, oracle):
     assert (out["labels"][0, 0] == 7).all() and (out["labels"][0, 1] == 8).all()
     # zero frames is a no-op
     ctx2.L.rvseg_segment_frames(ctx2.h, 0, None, None, None, None, None, None)
+
+
+@pytest.mark.parametrize("stride,toggles", [(1, dict()), (4, dict(feature_color_patch=0)), (2, dict(feature_normal=0, feature_height=0))])
+def test_rf_frames_strides_and_feature_toggles(gpu_ctx_factory, oracle, stride, toggles):
+    """The on-demand feature walk with other sample grids and without the colour patch / scalar features."""
+    W, H = 96, 64
+    rgb, depth = _small_case(5, W, H)
+    kw = dict(width=W, height=H, stride=stride, patch_size=9, patch_size_reduce=3, **toggles)
+    D = oracle.feature_length(oracle.default_params(**kw))
+    blob = synthetic.make_forest_bytes(seed=9, n_trees=5, leaves_per_tree=64, max_depth=9, D=D)
+    forest = oracle.Forest(blob)
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb[None], depth[None], calib)
+    want, _ = oracle.rf_frame(oracle.default_params(**kw), forest, 1, rgb, depth, calib)
+    assert np.array_equal(out["posteriors"][0], want)
