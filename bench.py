@@ -89,10 +89,26 @@ def cpu_baseline(n_frames, blob, rgb, depth, calib):
     for i in range(n_frames):
         O.segment_frame(p, forest, 0, rgb[i % len(rgb)], depth[i % len(depth)], calib, label_mode=1, unknown=[8])
     dt = time.perf_counter() - t0
-    return {"value": n_frames * W * H / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic 640x480 frames, RF (C=9) + 5-iter DenseCRF, oracle/rvseg_oracle.c, 1 thread"
-                      % n_frames,
-            "host_cpus": os.cpu_count()}
+    out = {"value": n_frames * W * H / dt / 1e6, "unit": "Mpix/s", "cores": 1, "kind": "port",
+           "sample": "%d synthetic 640x480 frames, RF (C=9) + 5-iter DenseCRF, oracle/rvseg_oracle.c, 1 thread"
+                     % n_frames,
+           "host_cpus": os.cpu_count()}
+    # the same port with frames spread over the host cores (one frame per thread;
+    # ctypes releases the GIL inside the C call).  Reported beside the 1-thread figure, not instead of it.
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, min(os.cpu_count() or 1, 32))
+        def one(i):
+            O.segment_frame(p, forest, 0, rgb[i % len(rgb)], depth[i % len(depth)], calib, label_mode=1, unknown=[8])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(one, range(threads)))
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": threads * W * H / dt / 1e6, "unit": "Mpix/s", "cores": threads,
+                            "sample": "%d frames, one per thread" % threads}
+    except Exception as e:  # the single-thread figure above is the contract; this one is extra
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def main():

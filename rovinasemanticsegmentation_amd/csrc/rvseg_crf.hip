@@ -74,7 +74,7 @@ static int capacity_log2_per_frame(const rvseg_ctx* ctx, int Npad, int d, bool s
 
 static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe) {
     if (d < 1 || d > 7) { ctx->err = "feature dimension must be in [1,7]"; return RVSEG_ERR_INVALID_ARG; }
-    if (n_frames > 32767) { ctx->err = "too many frames per chunk"; return RVSEG_ERR_INVALID_ARG; }
+    if (n_frames > 1022) { ctx->err = "at most 1022 frames per chunk (lower max_batch)"; return RVSEG_ERR_INVALID_ARG; }   // 10-bit frame field of the launch-order sort key
     const int Npad = (N + 3) / 4 * 4;
     const int cap_f_log2 = capacity_log2_per_frame(ctx, Npad, d, safe);
     const unsigned long long cap = (unsigned long long)n_frames << cap_f_log2;
