@@ -1066,9 +1066,38 @@ slice_kernel(LatticeDev L, int C, const float* __restrict__ values, float alpha,
     }
 }
 
+// The normaliser's slice (C == 1, seqCompute rounding, OUT_MODE 1) with the d+1 offsets and weights of a
+// point fetched as two wide rows.
+template <int DP1>
+__global__ void __launch_bounds__(256)
+slice_norm_kernel(LatticeDev L, const float* __restrict__ values, float alpha, float* __restrict__ out, long long n_points) {
+    if (L.counters[1]) return;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_points) return;
+    int offs[DP1];
+    float wts[DP1];
+    load_row<DP1>(L.offsets + p * DP1, offs);
+    load_row<DP1>(L.bary + p * DP1, wts);
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DP1; j++) {
+        const float t = wts[j] * values[offs[j]];
+        const float u = t * alpha;   // seqCompute :520
+        acc += u;
+    }
+    out[p] = (float)(1.0 / sqrt((double)acc + 1e-20));   // pairwise.cpp:55-56
+}
+
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
                   long long n_points, hipStream_t s) {
     const float alpha = 1.0f / (1 + powf(2, (float)-L.d));  // permutohedral.cpp:571
+    if (seq && out_mode == 1 && C == 1 && (L.d == 6 || L.d == 5 || L.d == 2)) {
+        const dim3 g1((unsigned)((n_points + 255) / 256)), b1(256);
+        if (L.d == 6) slice_norm_kernel<7><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
+        else if (L.d == 5) slice_norm_kernel<6><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
+        else slice_norm_kernel<3><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
+        return;
+    }
     const long long total = n_points * C;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
 #define RV_SLICE(SEQ, OM) slice_kernel<SEQ, OM><<<grid, block, 0, s>>>(L, C, values, alpha, neg_w, out, n_points)
