@@ -150,27 +150,34 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
         // read from LDS (prefetched one step ahead) and its final value written back.
         const int n_steps = 2 * (DM_CH - 1) + DM_CW;
         const bool row_ok = lane < DM_CH;
+        // Both passes are written without data-dependent branches: whether a lane updates a cell at step t
+        // depends only on its column index (lane-constant bounds), the result is a select.
         // ---- first pass: rows 1..H-1, columns 1..W-1 of the image, raster order
         {
             const int lr = lane;
             const int r = y0 + lr;
+            const bool row_upd = row_ok && r >= 1 && r < H;
+            const int lo = 1 - x0 > 0 ? 1 - x0 : 0, hi0 = W - x0 < DM_CW ? W - x0 : DM_CW;   // updated columns [lo, hi)
+            const int hi = hi0 < lo ? lo : hi0;
+            const int edge = W - 1 - x0;                  // tile column of the last image column
+            float* rowp = dist + (row_ok ? lr : 0) * DM_CW;
             float o1 = BIG, o2 = BIG, o3 = BIG;          // this lane's results at steps t-1, t-2, t-3
             int lc = -2 * lane;
-            float center_next = (row_ok && lc >= 0 && lc < DM_CW) ? dist[lr * DM_CW + lc] : BIG;
+            float center_next = (row_ok && lc >= 0 && lc < DM_CW) ? rowp[lc] : BIG;
             for (int t = 0; t < n_steps; t++, lc++) {
                 const float center = center_next;
                 const int lcn = lc + 1;
-                center_next = (row_ok && lcn >= 0 && lcn < DM_CW) ? dist[lr * DM_CW + lcn] : BIG;
+                const int lcn_c = lcn < 0 ? 0 : (lcn >= DM_CW ? DM_CW - 1 : lcn);
+                const float nxt = rowp[lcn_c];
+                center_next = (row_ok && (unsigned)lcn < (unsigned)DM_CW) ? nxt : BIG;
                 // results of the lane above: step t-1 -> column lc+1, t-2 -> lc, t-3 -> lc-1
-                float upRight = wave_shr1(o1, BIG), up = wave_shr1(o2, BIG), upLeft = wave_shr1(o3, BIG);
-                const int c = x0 + lc;
-                if (c + 1 >= W) upRight = BIG;           // prev[W] belongs to the next image row
-                const bool in_tile = row_ok && lc >= 0 && lc < DM_CW;
-                float out = in_tile ? center : BIG;
-                if (in_tile && r >= 1 && r < H && c >= 1 && c < W) {
-                    const float mn = fminf(fminf(upLeft + 1.4f, up + 1.0f), fminf(o1 + 1.0f, upRight + 1.4f));
-                    if (mn < center) { out = mn; dist[lr * DM_CW + lc] = mn; }
-                }
+                float upRight = wave_shr1(o1, BIG);
+                const float up = wave_shr1(o2, BIG), upLeft = wave_shr1(o3, BIG);
+                upRight = lc >= edge ? BIG : upRight;    // prev[W] belongs to the next image row
+                const float mn = fminf(fminf(upLeft + 1.4f, up + 1.0f), fminf(o1 + 1.0f, upRight + 1.4f));
+                const bool upd = row_upd && (unsigned)(lc - lo) < (unsigned)(hi - lo);
+                const float out = (upd && mn < center) ? mn : center;   // center is BIG outside the tile
+                if (upd) rowp[lc] = out;
                 o3 = o2; o2 = o1; o1 = out;
             }
         }
@@ -179,24 +186,30 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
         {
             const int lr = DM_CH - 1 - lane;
             const int r = y0 + lr;
+            const bool row_upd = row_ok && r >= 0 && r <= H - 2;
+            // mirrored column index cp = CW-1-lc; updated image columns 0..W-2  <=>  lc in [max(0,-x0), min(CW, W-1-x0))
+            const int llo = -x0 > 0 ? -x0 : 0, lhi = W - 1 - x0 < DM_CW ? W - 1 - x0 : DM_CW;
+            const int lo = DM_CW - lhi, hi1 = DM_CW - llo;   // the same range in cp
+            const int hi = hi1 < lo ? lo : hi1;
+            const int edge = DM_CW - 1 + x0;                 // cp of image column 0: cells with cp >= edge have no lowerLeft
+            float* rowp = dist + (row_ok ? lr : 0) * DM_CW;
             float o1 = BIG, o2 = BIG, o3 = BIG;
             int cp = -2 * lane;                          // mirrored column index
-            float center_next = (row_ok && cp >= 0 && cp < DM_CW) ? dist[lr * DM_CW + (DM_CW - 1 - cp)] : BIG;
+            float center_next = (row_ok && cp >= 0 && cp < DM_CW) ? rowp[DM_CW - 1 - cp] : BIG;
             for (int t = 0; t < n_steps; t++, cp++) {
                 const float center = center_next;
                 const int cpn = cp + 1;
-                center_next = (row_ok && cpn >= 0 && cpn < DM_CW) ? dist[lr * DM_CW + (DM_CW - 1 - cpn)] : BIG;
-                const int lc = DM_CW - 1 - cp;
+                const int cpn_c = cpn < 0 ? 0 : (cpn >= DM_CW ? DM_CW - 1 : cpn);
+                const float nxt = rowp[DM_CW - 1 - cpn_c];
+                center_next = (row_ok && (unsigned)cpn < (unsigned)DM_CW) ? nxt : BIG;
                 // lane l-1 is the row below: its step t-1 is column lc-1, t-2 -> lc, t-3 -> lc+1
-                float lowerLeft = wave_shr1(o1, BIG), lower = wave_shr1(o2, BIG), lowerRight = wave_shr1(o3, BIG);
-                const int c = x0 + lc;
-                if (c < 1) lowerLeft = BIG;              // next[-1] belongs to the previous image row
-                const bool in_tile = row_ok && cp >= 0 && cp < DM_CW;
-                float out = in_tile ? center : BIG;
-                if (in_tile && r >= 0 && r <= H - 2 && c >= 0 && c <= W - 2) {
-                    const float mn = fminf(fminf(lowerLeft + 1.4f, lower + 1.0f), fminf(o1 + 1.0f, lowerRight + 1.4f));
-                    if (mn < center) { out = mn; dist[lr * DM_CW + lc] = mn; }
-                }
+                float lowerLeft = wave_shr1(o1, BIG);
+                const float lower = wave_shr1(o2, BIG), lowerRight = wave_shr1(o3, BIG);
+                lowerLeft = cp >= edge ? BIG : lowerLeft;   // next[-1] belongs to the previous image row
+                const float mn = fminf(fminf(lowerLeft + 1.4f, lower + 1.0f), fminf(o1 + 1.0f, lowerRight + 1.4f));
+                const bool upd = row_upd && (unsigned)(cp - lo) < (unsigned)(hi - lo);
+                const float out = (upd && mn < center) ? mn : center;
+                if (upd) rowp[DM_CW - 1 - cp] = out;
                 o3 = o2; o2 = o1; o1 = out;
             }
         }
