@@ -112,7 +112,7 @@ __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long
 // ---------------------------------------------------------------------------------------------
 constexpr int LP_SET = 1024;       // block-local vertex set (LP_CHUNKS x 256 points x (d+1) keys, few distinct)
 constexpr int LP_MAX_PROBE = 24;
-constexpr int LP_CHUNKS = 4;       // consecutive 256-point chunks per block: the set (and its global slots) carries over
+constexpr int LP_CHUNKS = 8;       // consecutive 256-point chunks per block: the set (and its global slots) carries over
 
 template <int D>
 __global__ void __launch_bounds__(256)
