@@ -47,7 +47,13 @@ PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.m
 # stage name -> kernel whose PMC counters (profiles/*_pmc_batch64.json, collected with separate
 # rocprofv3 --pmc passes of this very command) give the HBM traffic per launch
 STAGE_KERNEL = {"splat": "rvseg::splat_group_kernel<0, 9, true>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
-                "rf_frames": "rvseg::rf_frames_kernel<false>"}
+                "rf_frames": "rvseg::rf_frames_lazy_kernel", "normal_feature": "rvseg::normal_feature_tiled_kernel",
+                "upsample_pack": "rvseg::upsample_pack_kernel<9>", "softmax": "rvseg::softmax_unary_kernel<9>",
+                "prep": "rvseg::prep_kernel"}
+# stages that are one kernel: the roofline object is reported for the largest of these.  (The lattice
+# build is a group of small kernels on a side stream, overlapped with feature extraction + forest
+# evaluation; its event time includes that sharing and is listed in stage_ms only.)
+SINGLE_KERNEL_STAGES = tuple(STAGE_KERNEL)
 
 
 def pmc_traffic(stage):
@@ -209,7 +215,8 @@ def main():
         value = n_gpus * px_per_step * args.steps / dt / 1e6
         # dominant stage and its roofline position
         launches = {"softmax": 1, "splat": CRF_ITERS, "blur": CRF_ITERS, "slice": CRF_ITERS, "mf_update": CRF_ITERS}
-        dom = max(stages, key=stages.get) if stages else None
+        cand = {k: v for k, v in stages.items() if k in SINGLE_KERNEL_STAGES}
+        dom = max(cand, key=cand.get) if cand else None
         roof = None
         if dom:
             k = launches.get(dom, 1)

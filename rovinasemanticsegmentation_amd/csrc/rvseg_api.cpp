@@ -245,6 +245,8 @@ void rvseg_destroy(rvseg_ctx* ctx) {
     dev_free(ctx->lab.cbrt);
     for (auto& b : ctx->pool) dev_free(b);
     for (auto ev : ctx->timer.events) (void)hipEventDestroy(ev);
+    if (ctx->timer.side0) (void)hipEventDestroy(ctx->timer.side0);
+    if (ctx->timer.side1) (void)hipEventDestroy(ctx->timer.side1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -331,6 +333,13 @@ int32_t rvseg_last_timing(const rvseg_ctx* ctx, char* names_out, size_t names_ca
             if (k == names.size()) { names.push_back(t.names[i]); ms.push_back(0.f); }
             ms[k] += v;
         }
+    }
+    if (t.side_used && t.side0 && t.side1) {   // the overlapped stage has its own pair of events
+        (void)hipEventSynchronize(t.side1);
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, t.side0, t.side1) != hipSuccess) v = 0.f;
+        names.push_back(t.side_name);
+        ms.push_back(v);
     }
     std::string joined;
     for (size_t i = 0; i < names.size(); i++) { if (i) joined += ';'; joined += names[i]; }

@@ -282,12 +282,10 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
 // ---------------------------------------------------------------------------------------------
 // per-frame CRF stage of the frame pipeline
 // ---------------------------------------------------------------------------------------------
-rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, const float* d_post,
-                        float* d_marg, int8_t* d_labels, hipStream_t s) {
+rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s) {
     CrfState* cs = crf_state(im);
     const FrameGeom& g = im->geom;
     const rvseg_params& p = ctx->params;
-    const DeviceForest& f = ctx->forest;
     const int N = g.W * g.H;
     rvseg_status st;
     // deferred overflow report of the previous asynchronous call
@@ -305,12 +303,21 @@ rvseg_status crf_frames(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rg
     FeatureSource fs{};
     fs.mode = 1; fs.cloud = im->cloud.as<float4>(); fs.rgb = d_rgb;
     fs.xyz_kernel = p.dcrf_xyz_kernel; fs.rgb_kernel = p.dcrf_rgb_kernel;
-    timer_mark(ctx, "lattice_build", s);
     if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
     RV_HIP(ctx, hipMemcpyAsync(cs->h_counters, lb.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     RV_HIP(ctx, hipEventRecord(cs->counters_ev, s));
     cs->counters_pending = true;
+    return RVSEG_OK;
+}
 
+rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* d_post, float* d_marg, int8_t* d_labels,
+                              hipStream_t s) {
+    CrfState* cs = crf_state(im);
+    const FrameGeom& g = im->geom;
+    const rvseg_params& p = ctx->params;
+    const DeviceForest& f = ctx->forest;
+    const int N = g.W * g.H;
+    rvseg_status st;
     const size_t frame_stride = (size_t)N * f.sum_classes;
     float* marg = d_marg;
     if (!marg) {

@@ -48,6 +48,11 @@ struct StageTimer {
     std::vector<hipEvent_t> events;  // pool; events[i] .. events[i+1] bracket stage i
     size_t used = 0;
     std::vector<float> ms;
+    // one stage may run on a side stream, overlapped with the stages above (the lattice build of the
+    // frame path): its own pair of events, reported under side_name
+    hipEvent_t side0 = nullptr, side1 = nullptr;
+    std::string side_name;
+    bool side_used = false;
 };
 
 }  // namespace rvseg

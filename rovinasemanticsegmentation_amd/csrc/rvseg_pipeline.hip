@@ -112,6 +112,9 @@ static void pipeline_free(Pipeline* im) {
     for (DevBuf* b : all) dev_free(*b);
     if (im->h_calibA) (void)hipHostFree(im->h_calibA);
     crf_state_free(im);
+    if (im->side) (void)hipStreamDestroy(im->side);
+    if (im->ev_fork) (void)hipEventDestroy(im->ev_fork);
+    if (im->ev_join) (void)hipEventDestroy(im->ev_join);
 }
 
 // A = R*Kinv, Eigen fixed 3x3 product accumulated left to right (feature_extractor.h:223)
@@ -142,6 +145,7 @@ void timer_reset(rvseg_ctx* ctx) {
     ctx->timer.names.clear();
     ctx->timer.ms.clear();
     ctx->timer.used = 0;
+    ctx->timer.side_used = false;
 }
 
 void timer_mark(rvseg_ctx* ctx, const char* name, hipStream_t s) {
@@ -180,6 +184,27 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     timer_mark(ctx, "prep", s);
     launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
                 need_cloud ? im->cloud.as<float4>() : nullptr, n, s);
+    static const bool no_overlap = std::getenv("RVSEG_NO_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_OVERLAP")) != 0;
+    bool forked = false;
+    if (p.use_dense_crf && !no_overlap) {
+        // fork: the lattice build runs on the side stream while this stream extracts features and walks the forest
+        if (!im->side) {
+            RV_HIP(ctx, hipStreamCreateWithFlags(&im->side, hipStreamNonBlocking));
+            RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_fork, hipEventDisableTiming));
+            RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_join, hipEventDisableTiming));
+            RV_HIP(ctx, hipEventCreate(&ctx->timer.side0));
+            RV_HIP(ctx, hipEventCreate(&ctx->timer.side1));
+        }
+        RV_HIP(ctx, hipEventRecord(im->ev_fork, s));
+        RV_HIP(ctx, hipStreamWaitEvent(im->side, im->ev_fork, 0));
+        RV_HIP(ctx, hipEventRecord(ctx->timer.side0, im->side));
+        if ((st = crf_frames_build(ctx, im, n, d_rgb, im->side)) != RVSEG_OK) { (void)hipStreamSynchronize(im->side); return st; }
+        RV_HIP(ctx, hipEventRecord(ctx->timer.side1, im->side));
+        RV_HIP(ctx, hipEventRecord(im->ev_join, im->side));
+        ctx->timer.side_name = "lattice_build";
+        ctx->timer.side_used = true;
+        forked = true;
+    }
     if (p.feature_normal) {
         timer_mark(ctx, "window_map", s);
         launch_window_map(g, im->cloud.as<float4>(), im->change.as<uint8_t>(), im->rect.as<uint8_t>(), n, s);
@@ -192,7 +217,13 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     timer_mark(ctx, "upsample_pack", s);
     launch_upsample_pack(g, f, im->up, im->low.as<float>(), post, n, s);
     if (p.use_dense_crf) {
-        st = crf_frames(ctx, im, n, d_rgb, post, d_marg, d_labels, s);
+        if (forked) {
+            RV_HIP(ctx, hipStreamWaitEvent(s, im->ev_join, 0));   // join
+        } else {
+            timer_mark(ctx, "lattice_build", s);
+            if ((st = crf_frames_build(ctx, im, n, d_rgb, s)) != RVSEG_OK) return st;
+        }
+        st = crf_frames_infer(ctx, im, n, post, d_marg, d_labels, s);
         if (st != RVSEG_OK) return st;
     } else if (d_labels) {
         timer_mark(ctx, "labels", s);
