@@ -971,7 +971,7 @@ blur_frames_kernel(LatticeDev L, int C, int reverse, float* __restrict__ a, floa
     float* ga = a + (size_t)f0 * C;
     float* gb = b + (size_t)f0 * C;
     if (lds) {
-        for (int i = threadIdx.x; i < n; i += 1024) tab[0][i] = ga[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) tab[0][i] = ga[i];
         __syncthreads();
     }
     int cur = 0;
@@ -981,7 +981,7 @@ blur_frames_kernel(LatticeDev L, int C, int reverse, float* __restrict__ a, floa
         const int* n2p = L.nb2 + (size_t)axis * L.m_bound + f0;
         const float* old_v = lds ? tab[cur] : (cur ? gb : ga);
         float* new_v = lds ? tab[cur ^ 1] : (cur ? ga : gb);
-        for (int i = threadIdx.x; i < n; i += 1024) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int v = i / C, c = i - v * C;
             const int n1 = n1p[v], n2 = n2p[v];
             const float x = n1 >= 0 ? old_v[(n1 - f0) * C + c] : 0.0f;
@@ -999,17 +999,19 @@ blur_frames_kernel(LatticeDev L, int C, int reverse, float* __restrict__ a, floa
         cur ^= 1;
     }
     if (lds) {
-        for (int i = threadIdx.x; i < n; i += 1024) gb[i] = tab[cur][i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) gb[i] = tab[cur][i];
     } else if (cur == 0) {
-        for (int i = threadIdx.x; i < n; i += 1024) gb[i] = ga[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) gb[i] = ga[i];
     }
 }
 
 // runs the d+1 axis passes; returns the buffer that holds the result
-float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s) {
+float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks) {
+    // small_blocks: the pass runs beside the feature kernels (lattice build on the side stream) and a
+    // 1024-thread block would wait for a whole free CU
     if (L.cap_f_mask + 1 <= 8192u) {   // at most 4096 vertices per frame: one block per frame is enough
-        if (seq) blur_frames_kernel<true><<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
-        else blur_frames_kernel<false><<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
+        if (seq) blur_frames_kernel<true><<<dim3((unsigned)L.n_frames), dim3(small_blocks ? 256 : 1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
+        else blur_frames_kernel<false><<<dim3((unsigned)L.n_frames), dim3(small_blocks ? 256 : 1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
         return b;
     }
     const long long total = (long long)L.m_bound * C;

@@ -184,7 +184,7 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     // norm = lattice.compute(ones) through seqCompute (1 row), then 1/sqrt(norm + 1e-20)
     ValueView none{nullptr, 0, 0};
     launch_splat(L, none, 1, 2, cs->val_a.as<float>(), s);
-    float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+    float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s, true);
     launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
     tr("normaliser");
     RV_HIP(ctx, hipGetLastError());
