@@ -754,7 +754,8 @@ template <int CC> struct SplatGroup { static constexpr int G = 64 / CC > 8 ? 8 :
 // A vertex's chain advances one tile per barrier, so the loads of a tile have to be in flight for
 // many tiles: {point, weight} pairs are fetched SPLAT_RE - 1 tiles ahead and the Q rows they point at
 // SPLAT_RR - 1 tiles ahead (a ring of 3 / 2 tiles stalled a memory round trip per tile).
-constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is written out for RE == 16
+constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is written out for RE == 16; RR must divide RE
+static_assert(SPLAT_RE % SPLAT_RR == 0, "ring positions are compile-time: the row ring has to divide the entry ring");
 
 template <int MODE, int CC, bool FULL>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
 __global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64)
