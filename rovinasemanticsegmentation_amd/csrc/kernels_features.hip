@@ -18,11 +18,16 @@ namespace rvseg {
 //   cloud : (R*Kinv)*(d*x, d*y, d) + t, NaN where depth is outside [d_min, d_max]
 //           (feature_extractor.h:209-223), stored float4 (x,y,z,0).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pair_fails(float z0, float z1) {
+    const float thr = (0.02f * (fabsf(z0) + 1.0f) * 2.0f);
+    return fabsf(z0 - z1) > thr || !finite_f(z0) || !finite_f(z1);
+}
+
 __global__ void __launch_bounds__(256)
 prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ cbrt_tab,
             const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth,
             const float* __restrict__ calibA,  // n x 12: A = R*Kinv (row-major 9), t (3)
-            uint32_t* __restrict__ lab, float4* __restrict__ cloud, int n_frames) {
+            uint32_t* __restrict__ lab, float4* __restrict__ cloud, uint8_t* __restrict__ change, int n_frames) {
     const size_t npix = (size_t)g.W * g.H;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= npix * (size_t)n_frames) return;
@@ -59,6 +64,30 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
         o.z = ((A[6] * m0 + A[7] * m1) + A[8] * m2) + A[11];
         o.w = 0.f;
         cloud[gid] = o;
+        if (change) {
+            // PCL's depth-change map (integral_image_normal.hpp, computeFeature): a pixel is marked when it
+            // belongs to a horizontal or vertical neighbour pair whose depths differ by more than
+            // 0.02*(|z|+1)*2 or contain a non-finite value.  The neighbours' z are recomputed from their depth
+            // with the very expression above, so they are the values those pixels store.
+            const uint16_t* dp = depth + (size_t)frame * npix;
+            auto z_at = [&](int rr, int cc) -> float {
+                const float dn = (float)dp[(size_t)rr * g.W + cc] / 1000.0f;
+                float n0, n1, n2;
+                if (dn < g.depth_min || dn > g.depth_max) {
+                    n0 = n1 = n2 = __int_as_float(0x7fc00000);
+                } else {
+                    n0 = dn * (float)cc; n1 = dn * (float)rr; n2 = dn;
+                }
+                return ((A[6] * n0 + A[7] * n1) + A[8] * n2) + A[11];
+            };
+            const int W = g.W, H = g.H, r = y, c = x;
+            const float z = o.z;
+            bool ch = false;
+            if (r <= H - 2 && c <= W - 2) ch = pair_fails(z, z_at(r, c + 1)) || pair_fails(z, z_at(r + 1, c));
+            if (!ch && c >= 1 && r <= H - 2) ch = pair_fails(z_at(r, c - 1), z);
+            if (!ch && r >= 1 && c <= W - 2) ch = pair_fails(z_at(r - 1, c), z);
+            change[gid] = ch ? 1 : 0;
+        }
     }
 }
 
@@ -75,37 +104,6 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
 constexpr int DM_TW = 64, DM_TH = 16, DM_APRON = 20;
 constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 104
 constexpr int DM_CH = DM_TH + 2 * DM_APRON;  // 56
-
-__device__ __forceinline__ float cloud_z(const float4* __restrict__ cloud, int W, int r, int c) {
-    return cloud[(size_t)r * W + c].z;
-}
-
-__device__ __forceinline__ bool pair_fails(float z0, float z1) {
-    const float thr = (0.02f * (fabsf(z0) + 1.0f) * 2.0f);
-    return fabsf(z0 - z1) > thr || !finite_f(z0) || !finite_f(z1);
-}
-
-// PCL's depth-change map (integral_image_normal.hpp, computeFeature): a pixel is marked when it
-// belongs to a horizontal or vertical neighbour pair whose depths differ by more than
-// 0.02*(|z|+1)*2 or contain a non-finite value.  One thread per pixel, gather formulation.
-__global__ void __launch_bounds__(256)
-change_map_kernel(FrameGeom g, const float4* __restrict__ cloud_all, uint8_t* __restrict__ change_all, int n_frames) {
-    const size_t npix = (size_t)g.W * g.H;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= npix * (size_t)n_frames) return;
-    const int frame = (int)(gid / npix);
-    const int pix = (int)(gid - (size_t)frame * npix);
-    const int W = g.W, H = g.H;
-    const int r = pix / W, c = pix - r * W;
-    const float4* cloud = cloud_all + (size_t)frame * npix;
-    const float z = cloud[pix].z;
-    bool change = false;
-    if (r <= H - 2 && c <= W - 2)
-        change = pair_fails(z, cloud_z(cloud, W, r, c + 1)) || pair_fails(z, cloud_z(cloud, W, r + 1, c));
-    if (!change && c >= 1 && r <= H - 2) change = pair_fails(cloud_z(cloud, W, r, c - 1), z);
-    if (!change && r >= 1 && c <= W - 2) change = pair_fails(cloud_z(cloud, W, r - 1, c), z);
-    change_all[gid] = change ? 1 : 0;
-}
 
 // value of the lane below in the wave (lane l takes lane l-1's); lane 0 takes `edge`
 __device__ __forceinline__ float wave_shr1(float v, float edge) {
@@ -394,17 +392,15 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
 
 // ---------------------------------------------------------------------------------------------
 void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
-                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, int n, hipStream_t s) {
+                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s) {
     LabCoeffs lc;
     for (int i = 0; i < 9; i++) lc.c[i] = lab.coeffs[i];
     const size_t total = (size_t)g.W * g.H * n;
     prep_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-        g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, n);
+        g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, d_change, n);
 }
 
 void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_change, uint8_t* d_rect, int n, hipStream_t s) {
-    const size_t total = (size_t)g.W * g.H * n;
-    change_map_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, d_cloud, d_change, n);
     const int tiles = ((g.W + DM_TW - 1) / DM_TW) * ((g.H + DM_TH - 1) / DM_TH);
     window_map_kernel<<<dim3((unsigned)(tiles * n)), dim3(64), 0, s>>>(g, d_change, d_rect);
 }

@@ -42,7 +42,7 @@ struct UpsampleTables {
 
 // ---- kernels_features.hip --------------------------------------------------------------------
 void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
-                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, int n, hipStream_t s);
+                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s);
 void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_change, uint8_t* d_rect, int n, hipStream_t s);
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
                            int n, hipStream_t s);

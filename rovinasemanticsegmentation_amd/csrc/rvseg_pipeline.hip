@@ -183,7 +183,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     }
     timer_mark(ctx, "prep", s);
     launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
-                need_cloud ? im->cloud.as<float4>() : nullptr, n, s);
+                need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s);
     static const bool no_overlap = std::getenv("RVSEG_NO_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_OVERLAP")) != 0;
     bool forked = false;
     if (p.use_dense_crf && !no_overlap) {
@@ -349,7 +349,7 @@ rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const ui
     RV_HIP(ctx, hipMemcpyAsync(im->in_depth.p, depth_mm, npix * 2, hipMemcpyHostToDevice, s));
     if ((st = upload_calib(ctx, im, calib, 1, s)) != RVSEG_OK) return st;
     launch_prep(g, ctx->lab, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
-                im->lab.as<uint32_t>(), im->cloud.as<float4>(), 1, s);
+                im->lab.as<uint32_t>(), im->cloud.as<float4>(), p.feature_normal ? im->change.as<uint8_t>() : nullptr, 1, s);
     if (p.feature_normal) {
         launch_window_map(g, im->cloud.as<float4>(), im->change.as<uint8_t>(), im->rect.as<uint8_t>(), 1, s);
         launch_normal_feature(g, im->cloud.as<float4>(), im->rect.as<uint8_t>(), im->nfeat.as<float>(), 1, s);
