@@ -110,7 +110,7 @@ __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long
 // ---------------------------------------------------------------------------------------------
 // Permutohedral::init per point (SSE branch semantics, fp32, no contraction)
 // ---------------------------------------------------------------------------------------------
-constexpr int LP_SET = 1024;       // block-local vertex set (LP_CHUNKS x 256 points x (d+1) keys, few distinct)
+constexpr int LP_SET = 512;        // block-local vertex set (LP_CHUNKS x 256 points x (d+1) keys, few distinct)
 constexpr int LP_MAX_PROBE = 24;
 constexpr int LP_CHUNKS = 8;       // consecutive 256-point chunks per block: the set (and its global slots) carries over
 
