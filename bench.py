@@ -4,15 +4,22 @@
 A "step" is one pass of the hot path over one batch of 64 synthetic 640x480 key frames
 (BASELINE.json configs[2], the HBM-roofline run; configs[1] -- a single frame -- is the same call
 with n = 1 and is reported as `latency_ms_single_frame`).  Inputs are resident in HBM before the
-timed region; every step writes CRF marginals and labels to HBM.  With --gpus N > 1 the driver
-starts one process per GPU (torch.distributed over RCCL): frames shard across ranks with no
-data-path collective except the final label gather to rank 0, i.e. weak scaling.
+timed region; every step writes CRF marginals and labels to HBM.
+
+Multi-GPU: one process per GPU, frames shard across ranks with no data-path
+collective except the final local-map label gather to rank 0 over RCCL, i.e. weak scaling.  Two ways
+in: the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment), or plain `python bench.py --gpus N`, which starts the N
+rank processes itself -- before anything in this process touches the GPU -- and fails loudly when the
+node has fewer than N devices.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,7 @@ CRF_ITERS = 5
 C_CLASSES = 9
 D_FEAT = 6
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MARGINAL_TOL = 1e-4    # BASELINE.json north_star
 
 # Algorithmic HBM bytes per full-resolution pixel and LAUNCH GROUP (SURVEY.md 8d, C = 9, d = 6).
 # `launches` = how many times the stage runs per step.
@@ -45,7 +53,7 @@ STAGE_BYTES_PER_PX = {
 PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.md 8d
 
 # stage name -> kernel whose PMC counters (profiles/*_pmc_batch64.json, collected with separate
-# rocprofv3 --pmc passes of this very command) give the HBM traffic per launch
+# rocprofv3 --pmc passes of this very command, profiles/scripts/pmc.sh) give the HBM traffic per launch
 STAGE_KERNEL = {"splat": "rvseg::splat_group_kernel<0, 9, true>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
                 "rf_frames": "rvseg::rf_frames_lazy_kernel", "normal_feature": "rvseg::normal_feature_tiled_kernel",
                 "upsample_pack": "rvseg::upsample_pack_kernel<9>", "softmax": "rvseg::softmax_unary_kernel<9>",
@@ -56,20 +64,34 @@ STAGE_KERNEL = {"splat": "rvseg::splat_group_kernel<0, 9, true>", "mf_update": "
 SINGLE_KERNEL_STAGES = tuple(STAGE_KERNEL)
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed PMC summary: FETCH_SIZE and
-    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane loads
-    (MI355X_MICROARCH.md, HBM section), which is what these kernels issue, so it is doubled."""
+def _latest(pattern):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_batch64.json")))
-    if not files or stage not in STAGE_KERNEL:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed PMC summary.  FETCH_SIZE and
+    WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte fabric request as 64 bytes
+    (MI355X_MICROARCH.md, HBM section); the factor applied to it is the one measured for the kernel's
+    own access shape by profiles/scripts/fetch_calibration (known byte counts, same counter), stored in
+    profiles/*_fetch_calibration.json: `stream16` for 16-B-per-lane streaming kernels, `gather36` for
+    the splat's 36-byte row gathers + 8-byte CSR stream."""
+    f = _latest("*_pmc_batch64.json")
+    if not f or stage not in STAGE_KERNEL:
         return None
-    with open(files[-1]) as fh:
+    with open(f) as fh:
         d = json.load(fh)
     r = d.get(STAGE_KERNEL[stage])
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
         return None
-    return (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
+    factor = 2.0
+    cal = _latest("*_fetch_calibration.json")
+    if cal:
+        with open(cal) as fh:
+            c = json.load(fh)
+        factor = float(c.get("factors", {}).get("gather36" if stage == "splat" else "stream16", factor))
+    return (factor * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
 
 
 def parse():
@@ -81,9 +103,52 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check of one batch frame")
+    ap.add_argument("--extras", default="default",
+                    help="comma list of extra measurements outside the timed region (N=1 only): host,localmap,config5; "
+                         "'default' = all that the build supports, 'none' = skip")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="CPU rehearsal of the multi-rank protocol (gloo, no GPU, no hot path): launcher, sharding, "
+                         "gather, barriers, max-over-ranks timing")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """Starts one rank process per GPU.  Nothing here initialises the GPU: the device count comes from
+    torch.cuda.device_count() (does not create a context on this image) and the children are started
+    with subprocess (never exec after GPU init)."""
+    n = args.gpus
+    if not args.rehearsal:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d requested but this node exposes %d GPU(s) (torch.cuda.device_count()); "
+                             "refusing to run ranks that would share a device\n" % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(n_frames, blob, rgb, depth, calib):
     """The CPU oracle (a port of the reference structure, single thread like the reference's
     inference path, src/segmenter.cpp:336-435) timed on this box's host cores."""
@@ -104,6 +169,7 @@ def cpu_baseline(n_frames, blob, rgb, depth, calib):
     try:
         from concurrent.futures import ThreadPoolExecutor
         threads = max(1, min(os.cpu_count() or 1, 32))
+
         def one(i):
             O.segment_frame(p, forest, 0, rgb[i % len(rgb)], depth[i % len(depth)], calib, label_mode=1, unknown=[8])
         t0 = time.perf_counter()
@@ -117,8 +183,66 @@ def cpu_baseline(n_frames, blob, rgb, depth, calib):
     return out
 
 
+def verify_frame(blob, rgb, depth, calib, marg, labels, frame):
+    """Post-run check (outside the timed region) of one frame of the LAST timed step against the CPU
+    oracle: labels bit-exact, marginals within the north star's 1e-4 (and whether they are bit-identical)."""
+    import numpy as np
+    from oracle import oracle as O
+    forest = O.Forest(blob)
+    p = O.default_params(dcrf_iterations=CRF_ITERS)
+    _, wm, wl = O.segment_frame(p, forest, 0, rgb[frame], depth[frame], calib, label_mode=1, unknown=[8])
+    diff = float(np.abs(marg - wm).max())
+    lab_ok = bool(np.array_equal(labels.ravel(), wl))
+    return {"ok": lab_ok and diff <= MARGINAL_TOL, "frame": int(frame), "labels_bit_exact": lab_ok,
+            "marginals_max_abs_diff": diff, "marginals_bit_exact": bool(np.array_equal(marg, wm)), "tolerance": MARGINAL_TOL}
+
+
+def rehearsal(args):
+    """The multi-rank protocol on CPU (gloo): what runs here is the launcher, the rank environment, frame
+    sharding, the preallocated gather and the barrier + max-over-ranks timing -- not the hot path."""
+    import torch
+    import torch.distributed as dist
+    from rovinasemanticsegmentation_amd.distributed import FrameGatherer, shard_frames
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n = args.frames
+    Hh, Ww = 6, 8
+    start, count = shard_frames(n * world, rank, world)
+    f = torch.arange(start, start + count).view(-1, 1)
+    local = ((f * 7 + torch.arange(Hh * Ww).view(1, -1)) % 120).to(torch.int8)
+    g = FrameGatherer(n * world, (Hh * Ww,), torch.int8, "cpu") if world > 1 else None
+    ok = True
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        fused = g.gather(local) if g else local
+        if rank == 0:
+            fa = torch.arange(n * world).view(-1, 1)
+            ok = ok and bool(torch.equal(fused, ((fa * 7 + torch.arange(Hh * Ww).view(1, -1)) % 120).to(torch.int8)))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "metric": "Mpix/s RF+5-iter DenseCRF @640x480 RGB-D", "value": None,
+                          "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                          "backend": "gloo", "gather_ok": ok, "steps": args.steps, "warmup": args.warmup, "seconds": dt}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.rehearsal:
+        sys.exit(rehearsal(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -130,7 +254,11 @@ def main():
     # multi-rank code path with all ranks on cuda:0 (never used by the driver)
     backend = os.environ.get("RVSEG_BENCH_BACKEND", "nccl")
     same_device = os.environ.get("RVSEG_BENCH_SAME_DEVICE", "0") == "1"
+    device_count = torch.cuda.device_count()
     dev_index = 0 if (same_device or world == 1) else local_rank
+    if dev_index >= device_count:
+        sys.stderr.write("bench.py: rank %d needs cuda:%d but the node exposes %d GPU(s)\n" % (rank, dev_index, device_count))
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
@@ -144,6 +272,7 @@ def main():
 
     import rovinasemanticsegmentation_amd as rv
     from rovinasemanticsegmentation_amd import synthetic
+    from rovinasemanticsegmentation_amd.distributed import FrameGatherer
 
     n = args.frames
     N = W * H
@@ -156,7 +285,8 @@ def main():
     d_depth = torch.from_numpy(depth_h.view(np.int16)).to(dev)
     d_marg = torch.empty((n, C_CLASSES * N), dtype=torch.float32, device=dev)
     d_labels = torch.empty((n, N), dtype=torch.int8, device=dev)
-    from rovinasemanticsegmentation_amd.distributed import gather_labels
+    # the local-map label gather: receive buffers exist once, before the timed region
+    gatherer = FrameGatherer(n * world, (N,), torch.int8, dev if backend == "nccl" else "cpu") if world > 1 else None
 
     ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=CRF_ITERS, label_mode=rv.capi.LABEL_CRF,
                      unknown_label=[8], max_batch=n, device=dev.index or 0,
@@ -170,7 +300,7 @@ def main():
         ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
                                   d_labels.data_ptr(), stream.cuda_stream)
         if world > 1:  # local-map label fusion: one gather to the fusion rank over xGMI
-            gather_labels(d_labels, n * world, dst=0)
+            gatherer.gather(d_labels if backend == "nccl" else d_labels.cpu())
 
     def barrier():
         if world > 1:
@@ -189,9 +319,21 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    async_status = ctx.poll_status(wait=True)   # hash overflow of the last step would show here
 
     # per-stage durations of the LAST step, from HIP events recorded on the launch stream
     stages = ctx.last_timing()
+    devices_seen = None
+    if world > 1:
+        devices_seen = [None] * world
+        dist.all_gather_object(devices_seen, {"rank": rank, "device": dev_index,
+                                              "name": torch.cuda.get_device_name(dev)})
+
+    verified = None
+    if rank == 0 and not args.no_verify:
+        vf = 9 % n
+        verified = verify_frame(blob, rgb_h, depth_h, calib, d_marg[vf].cpu().numpy(), d_labels[vf].cpu().numpy(), vf)
+
     # single-frame latency (configs[1]) -- outside the timed region
     lat = None
     stages_single = {}
@@ -205,10 +347,16 @@ def main():
         torch.cuda.synchronize(dev)
         lat = (time.perf_counter() - t1) / reps * 1e3
         stages_single = ctx.last_timing()
-        # overflow / async error check of the last call
-        ctx.segment_frames_device(1, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
-                                  d_labels.data_ptr(), stream.cuda_stream)
-        torch.cuda.synchronize(dev)
+        ctx.poll_status(wait=True)
+
+    extras = {}
+    if rank == 0 and n_gpus == 1 and args.extras != "none":
+        try:
+            from rovinasemanticsegmentation_amd import bench_extras
+            want = None if args.extras == "default" else set(args.extras.split(","))
+            extras = bench_extras.run(ctx, dev, blob, rgb_h, depth_h, calib, want)
+        except ImportError:
+            extras = {}
 
     if rank == 0:
         px_per_step = n * N
@@ -238,11 +386,16 @@ def main():
                                    "marginals + labels written to HBM" % n,
                        "frames_per_step_per_gpu": n, "label_gather": "rccl gather to rank 0" if world > 1 else "none"},
             "roofline": roof,
+            "verified": (verified["ok"] if verified else None), "verification": verified,
+            "async_status": "ok" if async_status == rv.capi.OK else str(async_status),
+            "world_size_seen": dist.get_world_size() if world > 1 else 1, "device_count": device_count,
+            "devices_seen": devices_seen,
             "pipeline_hbm_frac": round(PIPELINE_BYTES_PER_PX * value * 1e6 / n_gpus / (HBM_PEAK_GBS * 1e9), 5),
             "stage_ms_last_step": {k: round(v, 3) for k, v in stages.items()},
             "latency_ms_single_frame": round(lat, 3) if lat else None,
             "stage_ms_single_frame": {k: round(v, 3) for k, v in stages_single.items()},
         }
+        out.update(extras)
         if n_gpus == 1 and not args.no_cpu and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, blob, rgb_h, depth_h, calib)
         else:

@@ -57,7 +57,8 @@ typedef enum rvseg_status {
                                   compiled out in Release -> UB; here a clean error               */
     RVSEG_ERR_HIP = 5,         /* HIP runtime failure (message in rvseg_last_error)                */
     RVSEG_ERR_NO_DEVICE = 6,   /* no gfx950 device: the product never falls back to the CPU        */
-    RVSEG_ERR_CAPACITY = 7     /* lattice hash table / batch capacity exceeded                     */
+    RVSEG_ERR_CAPACITY = 7,    /* lattice hash table / batch / ensemble capacity exceeded          */
+    RVSEG_NOT_READY = 8        /* rvseg_poll_status without waiting: the work is still running      */
 } rvseg_status;
 
 /* Label rules found in the reference. */
@@ -89,10 +90,13 @@ typedef struct rvseg_params {
                                        for this many frames)                                        */
     int32_t device;                 /* HIP device ordinal                                           */
     int32_t lattice_capacity_log2;  /* hash-table slots per frame = 2^this; 0 = 2^12 (the Segmenter
-                                       kernel gives ~300 vertices / frame), -1 = worst case 2*N*(d+1).
-                                       Overflow is detected: host entry points retry with the worst
-                                       case, the _device entry point reports RVSEG_ERR_CAPACITY on the
-                                       next call                                                     */
+                                       kernel gives ~300 vertices / frame on the synthetic scenes, up to
+                                       ~2 200 on a real photo with a 1-10 m depth range), -1 = worst case
+                                       2*N*(d+1).  Overflow is detected, never silent: the context then
+                                       raises its capacity (x8 per step, up to the worst case) for all
+                                       later work; host entry points redo the chunk themselves, the
+                                       asynchronous _device entry point reports RVSEG_ERR_CAPACITY from
+                                       rvseg_poll_status (and from the next call)                     */
 } rvseg_params;
 
 /* Fills *p with the defaults of resources/config.json. */
@@ -111,6 +115,21 @@ int32_t rvseg_feature_length(const rvseg_ctx *ctx);
 /* ---- forest: replaces libf::RandomForest::read (libforest classifier.cpp:222-235) ------------ */
 rvseg_status rvseg_forest_load(rvseg_ctx *ctx, const char *path);
 rvseg_status rvseg_forest_load_mem(rvseg_ctx *ctx, const void *buf, size_t size);
+/* Host-only validation of a forest.dat image with the loader's own parser and limits (no context, no
+ * GPU): format, child links, split features < feature_length (<= 0: not checked), at most 64 trees
+ * (RVSEG_ERR_CAPACITY: libforest has no limit, the device evaluator does) and 64 classes.  err_out
+ * (optional) receives the message.  The reference has no such check: a bad model "will result in
+ * segfaults" (README.md:30). */
+rvseg_status rvseg_forest_check(const void *buf, size_t size, int32_t feature_length, int32_t *n_trees,
+                                int32_t *n_nodes_total, int32_t *max_depth, char *err_out, size_t err_cap);
+/* Replaces libf::RandomForest::write (classifier.cpp:210-220; DecisionTree::write :144-152): the loaded
+ * model in the reference's stream format, node for node -- a file read with rvseg_forest_load is
+ * written back byte for byte.  _mem: *size_out receives the needed size; out may be NULL to query. */
+rvseg_status rvseg_forest_write(const rvseg_ctx *ctx, const char *path);
+rvseg_status rvseg_forest_write_mem(const rvseg_ctx *ctx, void *out, size_t out_cap, size_t *size_out);
+/* The same writer without a context: parse `buf`, serialise it again (host only; used by the CPU tests
+ * to pin the writer against the reference-written golden files). */
+rvseg_status rvseg_forest_rewrite(const void *buf, size_t size, void *out, size_t out_cap, size_t *size_out);
 /* n_layers / class_counts describe the active mode (multi_layer or single). */
 rvseg_status rvseg_forest_info(const rvseg_ctx *ctx, int32_t *n_trees, int32_t *n_nodes_total,
                                int32_t *max_depth, int32_t *n_layers,
@@ -142,6 +161,15 @@ rvseg_status rvseg_segment_frames_device(rvseg_ctx *ctx, int32_t n_frames, const
                                          const uint16_t *d_depth_mm, const float *calib,
                                          float *d_posteriors_out, float *d_marginals_out,
                                          int8_t *d_labels_out, void *hip_stream);
+
+/* Status of the asynchronous work of the last rvseg_segment_frames_device call on this context (the
+ * lattice build is the only stage that can fail on the device: hash-table overflow).  wait != 0 blocks
+ * until that status is known (it does NOT wait for the outputs: synchronise the stream for those);
+ * wait == 0 returns RVSEG_NOT_READY while the build is still running.  RVSEG_ERR_CAPACITY: the outputs
+ * of that call are invalid (the kernels after an overflow exit without writing); the context has
+ * already raised its capacity, so repeating the call succeeds.  The reference has no counterpart (its
+ * hash table grows in place, permutohedral.cpp:59-79). */
+rvseg_status rvseg_poll_status(rvseg_ctx *ctx, int32_t wait);
 
 /* ---- CRF: replaces  DenseCRF crf(N,C); crf.setUnaryEnergy(U); crf.addPairwiseEnergy(feat,
  *      new PottsCompatibility(w)); Q = crf.inference(iters);  (src/segmenter.cpp:641-644;

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librvseg.so")
 
 RVSEG_MAX_LAYERS = 8
 
-OK, ERR_INVALID_ARG, ERR_IO, ERR_FORMAT, ERR_NO_FOREST, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(8)
+OK, ERR_INVALID_ARG, ERR_IO, ERR_FORMAT, ERR_NO_FOREST, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY, NOT_READY = range(9)
 LABEL_EVAL, LABEL_CRF, LABEL_NOCRF, LABEL_ARGMAX = range(4)
 
 # every symbol include/rvseg.h declares
@@ -22,6 +22,8 @@ SYMBOLS = [
     "rvseg_segment_frames_device", "rvseg_crf_infer", "rvseg_crf_infer_multi",
     "rvseg_lattice_build", "rvseg_lattice_filter", "rvseg_lattice_neighbours", "rvseg_last_timing",
     "rvseg_fuse_posteriors", "rvseg_label_values",
+    "rvseg_forest_check", "rvseg_forest_write", "rvseg_forest_write_mem", "rvseg_forest_rewrite",
+    "rvseg_poll_status",
 ]
 
 
@@ -90,6 +92,11 @@ def lib():
     L.rvseg_lattice_filter.argtypes = [vp, vp, i32, vp]
     L.rvseg_lattice_neighbours.argtypes = [vp, vp, vp, vp, vp, vp]
     L.rvseg_last_timing.argtypes = [vp, C.c_char_p, C.c_size_t, vp, i32]
+    L.rvseg_forest_check.argtypes = [vp, C.c_size_t, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t]
+    L.rvseg_forest_write.argtypes = [vp, C.c_char_p]
+    L.rvseg_forest_write_mem.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rvseg_forest_rewrite.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rvseg_poll_status.argtypes = [vp, i32]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library does not export it
     _lib = L
@@ -113,3 +120,26 @@ def check(ctx, status):
         msg = lib().rvseg_last_error(ctx)
         raise RvsegError(status, (msg or b"").decode("utf-8", "replace") or
                          lib().rvseg_status_string(status).decode())
+
+
+def forest_check(blob, feature_length=0):
+    """Host-only validation (no GPU): returns (status, message, info)."""
+    blob = bytes(blob)
+    nt, nn, md = C.c_int32(), C.c_int32(), C.c_int32()
+    err = C.create_string_buffer(512)
+    st = lib().rvseg_forest_check(blob, len(blob), feature_length, C.byref(nt), C.byref(nn), C.byref(md), err, 512)
+    return st, err.value.decode("utf-8", "replace"), {"n_trees": nt.value, "n_nodes": nn.value, "max_depth": md.value}
+
+
+def forest_rewrite(blob):
+    """Host-only: parse a forest.dat image and serialise it again with the library's writer."""
+    blob = bytes(blob)
+    size = C.c_size_t()
+    st = lib().rvseg_forest_rewrite(blob, len(blob), None, 0, C.byref(size))
+    if st != OK:
+        raise RvsegError(st, lib().rvseg_status_string(st).decode())
+    out = C.create_string_buffer(size.value)
+    st = lib().rvseg_forest_rewrite(blob, len(blob), out, size.value, C.byref(size))
+    if st != OK:
+        raise RvsegError(st, lib().rvseg_status_string(st).decode())
+    return out.raw[:size.value]

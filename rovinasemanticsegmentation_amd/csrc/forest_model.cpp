@@ -32,13 +32,6 @@ struct Reader {
     }
 };
 
-struct RawTree {
-    std::vector<int32_t> feat, left;
-    std::vector<float> thr;
-    std::vector<std::vector<float>> hist;
-    std::vector<std::vector<std::vector<float>>> mhist;
-};
-
 bool read_tree(Reader& r, RawTree& t) {
     int32_t n = r.len(4);
     t.feat.resize(n);
@@ -80,11 +73,18 @@ bool parse_forest(const void* buf, size_t size, int feature_length, ForestModel&
     int32_t T = r.i32();
     if (r.bad || T < 0 || (size_t)T * 20 > size) { err = "truncated or corrupt forest header"; return false; }
     if (T == 0) { err = "forest has no trees"; return false; }
+    if (T > kMaxTrees) {
+        // libforest has no tree limit; the device evaluator keeps at most 16 leaf rows in each of a
+        // point's 4 lanes (kernels_rf.hip), so larger ensembles are refused instead of mis-evaluated
+        err = "forest has " + std::to_string(T) + " trees; at most " + std::to_string(kMaxTrees) + " are supported";
+        return false;
+    }
     out.n_trees = T;
+    out.raw.resize((size_t)T);
     bool have_single = true, have_multi = true, first_leaf = true;
 
     for (int t = 0; t < T; t++) {
-        RawTree raw;
+        RawTree& raw = out.raw[(size_t)t];
         if (!read_tree(r, raw)) { err = "truncated forest stream in tree " + std::to_string(t); return false; }
         const size_t n = raw.left.size();
         if (n == 0 || raw.feat.size() != n || raw.thr.size() != n || raw.hist.size() != n || raw.mhist.size() != n) {
@@ -172,42 +172,25 @@ std::vector<uint8_t> serialize_forest(const ForestModel& m) {
     std::vector<uint8_t> o;
     auto put_i = [&](int32_t v) { uint8_t b[4]; std::memcpy(b, &v, 4); o.insert(o.end(), b, b + 4); };
     auto put_f = [&](float v) { uint8_t b[4]; std::memcpy(b, &v, 4); o.insert(o.end(), b, b + 4); };
-    int sumC = 0;
-    for (int c : m.layer_classes) sumC += c;
-    put_i(m.n_trees);
-    for (int t = 0; t < m.n_trees; t++) {
-        const int32_t base = m.roots[t];
-        const int32_t end = t + 1 < m.n_trees ? m.roots[t + 1] : (int32_t)m.nodes.size();
-        const int32_t n = end - base;
-        put_i(n);
-        for (int32_t k = 0; k < n; k++) put_i(m.nodes[base + k].feature);
-        put_i(n);
-        for (int32_t k = 0; k < n; k++) put_f(m.nodes[base + k].threshold);
-        put_i(n);
-        for (int32_t k = 0; k < n; k++) put_i(m.nodes[base + k].left ? m.nodes[base + k].left - base : 0);
-        put_i(n);
-        for (int32_t k = 0; k < n; k++) {
-            const DeviceNode& dn = m.nodes[base + k];
-            if (dn.left == 0 && m.single_classes > 0) {
-                put_i(m.single_classes);
-                for (int c = 0; c < m.single_classes; c++) put_f(m.single_hist[(size_t)dn.leaf_row * m.single_classes + c]);
-            } else {
-                put_i(0);
-            }
+    put_i((int32_t)m.raw.size());                      // writeBinary(stream, getSize()), classifier.cpp:213
+    for (const RawTree& t : m.raw) {                   // DecisionTree::write, classifier.cpp:144-152
+        put_i((int32_t)t.feat.size());
+        for (int32_t v : t.feat) put_i(v);
+        put_i((int32_t)t.thr.size());
+        for (float v : t.thr) put_f(v);
+        put_i((int32_t)t.left.size());
+        for (int32_t v : t.left) put_i(v);
+        put_i((int32_t)t.hist.size());
+        for (const auto& h : t.hist) {
+            put_i((int32_t)h.size());
+            for (float v : h) put_f(v);
         }
-        put_i(n);
-        for (int32_t k = 0; k < n; k++) {
-            const DeviceNode& dn = m.nodes[base + k];
-            if (dn.left == 0 && !m.layer_classes.empty()) {
-                put_i((int32_t)m.layer_classes.size());
-                size_t off = (size_t)dn.leaf_row * sumC;
-                for (int c : m.layer_classes) {
-                    put_i(c);
-                    for (int k2 = 0; k2 < c; k2++) put_f(m.multi_hist[off + k2]);
-                    off += c;
-                }
-            } else {
-                put_i(0);
+        put_i((int32_t)t.mhist.size());
+        for (const auto& mh : t.mhist) {
+            put_i((int32_t)mh.size());
+            for (const auto& h : mh) {
+                put_i((int32_t)h.size());
+                for (float v : h) put_f(v);
             }
         }
     }

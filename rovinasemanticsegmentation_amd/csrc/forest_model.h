@@ -24,7 +24,22 @@ struct DeviceNode {
                        // coordinates of `feature` (channel << 16 | dy << 8 | dx), see upload_forest
 };
 
+// One tree exactly as the stream holds it (libforest classifiers.h:191-206): node order, leaf
+// feature / threshold slots and inner-node histograms included, so that a model read from a file
+// is written back byte for byte (RandomForest::write, classifier.cpp:144-152,210-220).
+struct RawTree {
+    std::vector<int32_t> feat, left;
+    std::vector<float> thr;
+    std::vector<std::vector<float>> hist;
+    std::vector<std::vector<std::vector<float>>> mhist;
+};
+
+// Limits of the device evaluator (kernels_rf.hip: leaf_rows[16] x 4 lanes per point; one lane per class).
+constexpr int kMaxTrees = 64;
+constexpr int kMaxClasses = 64;
+
 struct ForestModel {
+    std::vector<RawTree> raw;             // the stream's own trees (what serialize_forest writes)
     int n_trees = 0;
     int max_depth = 0;                    // longest root->leaf path, in edges
     std::vector<int32_t> roots;           // per tree: index of its root in `nodes`
@@ -43,8 +58,8 @@ struct ForestModel {
 bool parse_forest(const void* buf, size_t size, int feature_length, ForestModel& out,
                   std::string& err);
 
-// Serialises a forest in the reference's format (RandomForest::write, classifier.cpp:210-220).
-// Trees are written in the model's breadth-first order, which the reference reader accepts.
+// Serialises a forest in the reference's format (RandomForest::write, classifier.cpp:210-220;
+// DecisionTree::write :144-152; writeBinary io.h:34-108): the trees of `m.raw`, node for node.
 std::vector<uint8_t> serialize_forest(const ForestModel& m);
 
 }  // namespace rvseg

@@ -100,7 +100,8 @@ static rvseg_status upload_forest(rvseg_ctx* ctx) {
         f.class_counts[0] = m.single_classes;
         f.sum_classes = m.single_classes;
     }
-    if (f.sum_classes > 64) { ctx->err = "more than 64 classes over all layers is not supported"; return RVSEG_ERR_FORMAT; }
+    if (f.sum_classes > kMaxClasses) { ctx->err = "more than 64 classes over all layers is not supported"; return RVSEG_ERR_FORMAT; }
+    if (m.n_trees > kMaxTrees) { ctx->err = "more than 64 trees are not supported"; return RVSEG_ERR_CAPACITY; }   // parse_forest refuses these already
     const std::vector<float>& hist = multi ? m.multi_hist : m.single_hist;
     rvseg_status st;
     if ((st = dev_alloc(ctx, f.nodes, m.nodes.size() * sizeof(DeviceNode))) != RVSEG_OK) return st;
@@ -127,6 +128,20 @@ static rvseg_status upload_forest(rvseg_ctx* ctx) {
     RV_HIP(ctx, hipMemcpy(f.roots.p, m.roots.data(), m.roots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RV_HIP(ctx, hipMemcpy(f.hist.p, hist.data(), hist.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->forest_loaded = true;
+    return RVSEG_OK;
+}
+
+static rvseg_status parse_error_status(const std::string& err) {
+    if (err == "forest has no trees") return RVSEG_ERR_NO_FOREST;
+    if (err.find("at most") != std::string::npos && err.find("trees") != std::string::npos) return RVSEG_ERR_CAPACITY;
+    return RVSEG_ERR_FORMAT;
+}
+
+static rvseg_status copy_out(const std::vector<uint8_t>& bytes, void* out, size_t out_cap, size_t* size_out) {
+    if (size_out) *size_out = bytes.size();
+    if (!out) return RVSEG_OK;                       // size query
+    if (out_cap < bytes.size()) return RVSEG_ERR_INVALID_ARG;
+    std::memcpy(out, bytes.data(), bytes.size());
     return RVSEG_OK;
 }
 
@@ -166,6 +181,7 @@ const char* rvseg_status_string(rvseg_status s) {
         case RVSEG_ERR_HIP: return "HIP runtime error";
         case RVSEG_ERR_NO_DEVICE: return "no HIP device";
         case RVSEG_ERR_CAPACITY: return "capacity exceeded";
+        case RVSEG_NOT_READY: return "not ready";
     }
     return "unknown";
 }
@@ -190,7 +206,9 @@ rvseg_status rvseg_create(const rvseg_params* params, rvseg_ctx** out) {
     if (p.width < 4 || p.height < 4 || p.width > 16384 || p.height > 16384) return fail(RVSEG_ERR_INVALID_ARG, "bad image size");
     if (p.stride < 1 || p.stride > 64) return fail(RVSEG_ERR_INVALID_ARG, "bad stride");
     if (!(p.depth_min > 0.f) || !(p.depth_max >= p.depth_min)) return fail(RVSEG_ERR_INVALID_ARG, "bad depth range");
-    if (p.patch_size_reduce < 1 || p.patch_size_reduce > 32 || p.patch_size < 1) return fail(RVSEG_ERR_INVALID_ARG, "bad patch size");
+    // RT_MAXR (rvseg_kernels.h): the resize tables hold 16 cells per axis
+    if (p.patch_size_reduce < 1 || p.patch_size_reduce > 16 || p.patch_size < 1) return fail(RVSEG_ERR_INVALID_ARG, "bad patch size (patch_size_reduce must be in [1,16])");
+    if (p.lattice_capacity_log2 > 30) return fail(RVSEG_ERR_INVALID_ARG, "bad lattice_capacity_log2");
     // The reflected border is patch_size wide (feature_extractor.h:37,130): the largest ROI half
     // size int(patch_size / (2*depth_min)) must fit into it, and a single reflection must do.
     if (p.feature_color_patch) {
@@ -261,11 +279,60 @@ rvseg_status rvseg_forest_load_mem(rvseg_ctx* ctx, const void* buf, size_t size)
     std::string err;
     if (!parse_forest(buf, size, ctx->feature_length, m, err)) {
         ctx->err = err;
-        return m.n_trees == 0 && err == "forest has no trees" ? RVSEG_ERR_NO_FOREST : RVSEG_ERR_FORMAT;
+        return parse_error_status(err);
     }
+    // the device copy of the previous model may still be read by work the caller enqueued on its own
+    // stream (rvseg_segment_frames_device returns without synchronising)
+    RV_HIP(ctx, hipDeviceSynchronize());
     ctx->host_forest = std::move(m);
     ctx->forest_loaded = false;
     return upload_forest(ctx);
+}
+
+rvseg_status rvseg_forest_check(const void* buf, size_t size, int32_t feature_length, int32_t* n_trees,
+                                int32_t* n_nodes_total, int32_t* max_depth, char* err_out, size_t err_cap) {
+    ForestModel m;
+    std::string err;
+    rvseg_status st = RVSEG_OK;
+    if (!parse_forest(buf, size, feature_length > 0 ? feature_length : 0x7fffffff, m, err)) {
+        st = parse_error_status(err);
+    } else {
+        int sum_multi = 0;
+        for (int c : m.layer_classes) sum_multi += c;
+        if (m.single_classes > kMaxClasses || sum_multi > kMaxClasses || m.layer_classes.size() > RVSEG_MAX_LAYERS) {
+            err = "more than 64 classes or 8 layers are not supported";
+            st = RVSEG_ERR_FORMAT;
+        }
+    }
+    if (err_out && err_cap) std::snprintf(err_out, err_cap, "%s", err.c_str());
+    if (st != RVSEG_OK) return st;
+    if (n_trees) *n_trees = m.n_trees;
+    if (n_nodes_total) *n_nodes_total = (int32_t)m.nodes.size();
+    if (max_depth) *max_depth = m.max_depth;
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_forest_rewrite(const void* buf, size_t size, void* out, size_t out_cap, size_t* size_out) {
+    ForestModel m;
+    std::string err;
+    if (!parse_forest(buf, size, 0x7fffffff, m, err)) return parse_error_status(err);
+    return copy_out(serialize_forest(m), out, out_cap, size_out);
+}
+
+rvseg_status rvseg_forest_write_mem(const rvseg_ctx* ctx, void* out, size_t out_cap, size_t* size_out) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) return RVSEG_ERR_NO_FOREST;
+    return copy_out(serialize_forest(ctx->host_forest), out, out_cap, size_out);
+}
+
+rvseg_status rvseg_forest_write(const rvseg_ctx* ctx, const char* path) {
+    if (!ctx || !path) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->forest_loaded) return RVSEG_ERR_NO_FOREST;
+    const std::vector<uint8_t> bytes = serialize_forest(ctx->host_forest);
+    std::ofstream os(path, std::ios::binary);
+    if (!os.is_open()) return RVSEG_ERR_IO;          // libf::Exception("Could not open file."), io.h:118-121
+    os.write(reinterpret_cast<const char*>(bytes.data()), (std::streamsize)bytes.size());
+    return os.good() ? RVSEG_OK : RVSEG_ERR_IO;
 }
 
 rvseg_status rvseg_forest_load(rvseg_ctx* ctx, const char* path) {

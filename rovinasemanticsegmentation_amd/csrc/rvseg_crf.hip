@@ -29,13 +29,20 @@ struct CrfState {
     bool counters_pending = false;
 };
 
-static CrfState* crf_state(Pipeline* im) {
+static rvseg_status crf_state(rvseg_ctx* ctx, Pipeline* im, CrfState** out) {
     if (!im->crf) {
-        im->crf = new CrfState();
-        (void)hipHostMalloc((void**)&im->crf->h_counters, 4 * sizeof(int), hipHostMallocDefault);
-        (void)hipEventCreateWithFlags(&im->crf->counters_ev, hipEventDisableTiming);
+        CrfState* cs = new CrfState();
+        if (!hip_ok(ctx, hipHostMalloc((void**)&cs->h_counters, 4 * sizeof(int), hipHostMallocDefault), "hipHostMalloc(counters)") ||
+            !hip_ok(ctx, hipEventCreateWithFlags(&cs->counters_ev, hipEventDisableTiming), "hipEventCreate(counters)")) {
+            if (cs->h_counters) (void)hipHostFree(cs->h_counters);
+            delete cs;
+            return RVSEG_ERR_HIP;
+        }
+        cs->h_counters[0] = cs->h_counters[1] = cs->h_counters[2] = cs->h_counters[3] = 0;
+        im->crf = cs;
     }
-    return im->crf;
+    *out = im->crf;
+    return RVSEG_OK;
 }
 
 static void lattice_free(LatticeBufs& b) {
@@ -62,14 +69,21 @@ static int ceil_log2(unsigned long long v) {
     return b;
 }
 
-// per-frame hash capacity: params.lattice_capacity_log2 > 0 as given; 0 = 2^18; < 0 or `safe` =
-// enough for every point to own d+1 private vertices at load factor 1/2
+// per-frame hash capacity: params.lattice_capacity_log2 > 0 as given; 0 = 2^12; < 0 or `safe` =
+// enough for every point to own d+1 private vertices at load factor 1/2.  Every overflow seen on this
+// context has raised cap_boost by 3 (x8 slots), so a scene that does not fit is paid for once.
 static int capacity_log2_per_frame(const rvseg_ctx* ctx, int Npad, int d, bool safe) {
     const int safe_log2 = ceil_log2(2ull * (unsigned long long)Npad * (d + 1));
     int want = ctx->params.lattice_capacity_log2;
     if (safe || want < 0) return safe_log2;
-    if (want == 0) want = 12;   // the Segmenter kernel yields ~300 vertices per 640x480 frame
+    if (want == 0) want = 12;   // the Segmenter kernel yields ~300 vertices per synthetic 640x480 frame
+    if (ctx->impl) want += reinterpret_cast<const Pipeline*>(ctx->impl)->cap_boost;
     return want < safe_log2 ? want : safe_log2;
+}
+
+static bool capacity_is_worst_case(const rvseg_ctx* ctx, int N, int d) {
+    const int Npad = (N + 3) / 4 * 4;
+    return capacity_log2_per_frame(ctx, Npad, d, false) == capacity_log2_per_frame(ctx, Npad, d, true);
 }
 
 static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe) {
@@ -282,21 +296,39 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
 // ---------------------------------------------------------------------------------------------
 // per-frame CRF stage of the frame pipeline
 // ---------------------------------------------------------------------------------------------
+rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait) {
+    CrfState* cs = im->crf;
+    if (!cs || !cs->counters_pending) return RVSEG_OK;
+    if (wait) {
+        RV_HIP(ctx, hipEventSynchronize(cs->counters_ev));
+    } else {
+        const hipError_t e = hipEventQuery(cs->counters_ev);
+        if (e == hipErrorNotReady) return RVSEG_NOT_READY;
+        RV_HIP(ctx, e);
+    }
+    cs->counters_pending = false;
+    if (cs->h_counters[1]) {
+        const FrameGeom& g = im->geom;
+        const bool was_worst = capacity_is_worst_case(ctx, g.W * g.H, 6);
+        im->cap_boost += 3;
+        ctx->err = was_worst ? "lattice hash table overflowed at its worst-case capacity (internal error)"
+                             : "lattice hash table overflowed: the outputs of that call are invalid; the context has raised its "
+                               "capacity (x8 slots per frame), repeat the call (or set params.lattice_capacity_log2 = -1)";
+        return RVSEG_ERR_CAPACITY;
+    }
+    return RVSEG_OK;
+}
+
 rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s) {
-    CrfState* cs = crf_state(im);
+    CrfState* cs;
+    rvseg_status st = crf_state(ctx, im, &cs);
+    if (st != RVSEG_OK) return st;
     const FrameGeom& g = im->geom;
     const rvseg_params& p = ctx->params;
     const int N = g.W * g.H;
-    rvseg_status st;
-    // deferred overflow report of the previous asynchronous call
-    if (cs->counters_pending) {
-        RV_HIP(ctx, hipEventSynchronize(cs->counters_ev));
-        cs->counters_pending = false;
-        if (cs->h_counters[1]) {
-            ctx->err = "lattice hash table overflowed in the previous call (raise params.lattice_capacity_log2 or use -1)";
-            return RVSEG_ERR_CAPACITY;
-        }
-    }
+    // status of the previous asynchronous build (an earlier chunk of this call, or an earlier call whose
+    // status nobody polled): its outputs were invalid, so this call must not pass for a clean one
+    if ((st = crf_frames_status(ctx, im, true)) != RVSEG_OK) return st;
     if (cs->lat.size() < 1) cs->lat.resize(1);
     LatticeBufs& lb = cs->lat[0];
     if ((st = lattice_prepare(ctx, lb, 6, N, n, false)) != RVSEG_OK) return st;
@@ -312,7 +344,9 @@ rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
 
 rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* d_post, float* d_marg, int8_t* d_labels,
                               hipStream_t s) {
-    CrfState* cs = crf_state(im);
+    CrfState* cs;
+    rvseg_status st0 = crf_state(ctx, im, &cs);
+    if (st0 != RVSEG_OK) return st0;
     const FrameGeom& g = im->geom;
     const rvseg_params& p = ctx->params;
     const DeviceForest& f = ctx->forest;
@@ -359,8 +393,7 @@ static rvseg_status crf_enter(rvseg_ctx* ctx, Pipeline** im_out, CrfState** cs_o
         im->bare = true;
     }
     *im_out = reinterpret_cast<Pipeline*>(ctx->impl);
-    *cs_out = crf_state(*im_out);
-    return RVSEG_OK;
+    return crf_state(ctx, *im_out, cs_out);
 }
 
 extern "C" {

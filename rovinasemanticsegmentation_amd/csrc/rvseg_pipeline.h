@@ -13,8 +13,18 @@ struct Pipeline {
     UpsampleTables up;
     // per-chunk device buffers (grow-only, sized for up to max_batch frames)
     DevBuf calibA, lab, cloud, change, rect, nfeat, low, post, marg, labels, in_rgb, in_depth, dump, valid;
-    float* h_calibA = nullptr;  // pinned staging for the per-frame A = R*Kinv, t
-    size_t h_calibA_bytes = 0;
+    // pinned staging for the per-frame A = R*Kinv, t.  The device entry point returns without
+    // synchronising, so a slot may only be rewritten once the copy that read it has run: a small ring,
+    // each slot guarded by an event recorded behind its H2D copy
+    static constexpr int CALIB_RING = 4;
+    float* h_calibA[CALIB_RING] = {};
+    size_t h_calibA_bytes[CALIB_RING] = {};
+    hipEvent_t calib_ev[CALIB_RING] = {};
+    bool calib_ev_live[CALIB_RING] = {};
+    int calib_next = 0;
+    // raised (by 3 = x8 slots) every time a lattice build overflows its hash table; applies to all later
+    // builds of this context (include/rvseg.h, lattice_capacity_log2)
+    int cap_boost = 0;
     CrfState* crf = nullptr;
     bool bare = false;  // created by a CRF entry point: frame tables not initialised yet
     // the lattice build depends only on the cloud and the colours, not on the forest: it runs on a
@@ -33,6 +43,9 @@ void crf_state_free(Pipeline* im);
 // the back-projected cloud and the colours
 // part 1 (lattice + normaliser; needs the cloud only) and part 2 (mean field per layer + labels)
 rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s);
+// Status of the last enqueued frame build (consumes it): RVSEG_OK, RVSEG_NOT_READY (only without `wait`)
+// or RVSEG_ERR_CAPACITY after raising im->cap_boost.  RVSEG_OK when nothing is pending.
+rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait);
 rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* d_post, float* d_marg, int8_t* d_labels,
                               hipStream_t s);
 

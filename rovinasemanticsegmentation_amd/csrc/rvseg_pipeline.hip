@@ -110,7 +110,10 @@ static void pipeline_free(Pipeline* im) {
                      &im->calibA, &im->lab, &im->cloud, &im->rect, &im->nfeat, &im->low, &im->post, &im->marg,
                      &im->labels, &im->in_rgb, &im->in_depth, &im->dump, &im->valid, &im->change};
     for (DevBuf* b : all) dev_free(*b);
-    if (im->h_calibA) (void)hipHostFree(im->h_calibA);
+    for (int i = 0; i < Pipeline::CALIB_RING; i++) {
+        if (im->calib_ev[i]) { (void)hipEventSynchronize(im->calib_ev[i]); (void)hipEventDestroy(im->calib_ev[i]); }
+        if (im->h_calibA[i]) (void)hipHostFree(im->h_calibA[i]);
+    }
     crf_state_free(im);
     if (im->side) (void)hipStreamDestroy(im->side);
     if (im->ev_fork) (void)hipEventDestroy(im->ev_fork);
@@ -127,16 +130,26 @@ static void calib_to_A(const float* calib, float* out12) {
 }
 
 static rvseg_status upload_calib(rvseg_ctx* ctx, Pipeline* im, const float* calib, int n, hipStream_t s) {
-    if ((size_t)n * 12 * sizeof(float) > im->h_calibA_bytes) {
-        if (im->h_calibA) (void)hipHostFree(im->h_calibA);
-        im->h_calibA = nullptr;
-        im->h_calibA_bytes = (size_t)n * 12 * sizeof(float);
-        RV_HIP(ctx, hipHostMalloc((void**)&im->h_calibA, im->h_calibA_bytes, hipHostMallocDefault));
+    const int slot = im->calib_next;
+    im->calib_next = (slot + 1) % Pipeline::CALIB_RING;
+    if (!im->calib_ev[slot]) RV_HIP(ctx, hipEventCreateWithFlags(&im->calib_ev[slot], hipEventDisableTiming));
+    // the copy that last read this slot must have run before the host rewrites (or frees) it
+    if (im->calib_ev_live[slot]) { RV_HIP(ctx, hipEventSynchronize(im->calib_ev[slot])); im->calib_ev_live[slot] = false; }
+    const size_t bytes = (size_t)n * 12 * sizeof(float);
+    if (bytes > im->h_calibA_bytes[slot]) {
+        if (im->h_calibA[slot]) (void)hipHostFree(im->h_calibA[slot]);
+        im->h_calibA[slot] = nullptr;
+        im->h_calibA_bytes[slot] = 0;
+        RV_HIP(ctx, hipHostMalloc((void**)&im->h_calibA[slot], bytes, hipHostMallocDefault));
+        im->h_calibA_bytes[slot] = bytes;
     }
-    for (int i = 0; i < n; i++) calib_to_A(calib + (size_t)i * 21, im->h_calibA + (size_t)i * 12);
-    rvseg_status st = dev_reserve(ctx, im->calibA, (size_t)n * 12 * sizeof(float));
+    float* h = im->h_calibA[slot];
+    for (int i = 0; i < n; i++) calib_to_A(calib + (size_t)i * 21, h + (size_t)i * 12);
+    rvseg_status st = dev_reserve(ctx, im->calibA, bytes);   // (a reallocation frees with hipFree, which waits for the device)
     if (st != RVSEG_OK) return st;
-    RV_HIP(ctx, hipMemcpyAsync(im->calibA.p, im->h_calibA, (size_t)n * 12 * sizeof(float), hipMemcpyHostToDevice, s));
+    RV_HIP(ctx, hipMemcpyAsync(im->calibA.p, h, bytes, hipMemcpyHostToDevice, s));
+    RV_HIP(ctx, hipEventRecord(im->calib_ev[slot], s));
+    im->calib_ev_live[slot] = true;
     return RVSEG_OK;
 }
 
@@ -306,12 +319,24 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
         if (labels_out && (st = dev_reserve(ctx, im->labels, npix * L * n)) != RVSEG_OK) return st;
         RV_HIP(ctx, hipMemcpyAsync(im->in_rgb.p, rgb + (size_t)start * npix * 3, npix * 3 * n, hipMemcpyHostToDevice, s));
         RV_HIP(ctx, hipMemcpyAsync(im->in_depth.p, depth_mm + (size_t)start * npix, npix * 2 * n, hipMemcpyHostToDevice, s));
-        timer_reset(ctx);
-        if ((st = upload_calib(ctx, im, calib + (size_t)start * 21, n, s)) != RVSEG_OK) return st;
-        st = run_chunk(ctx, im, n, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
-                       im->post.as<float>(), want_marg ? im->marg.as<float>() : nullptr,
-                       labels_out ? im->labels.as<int8_t>() : nullptr, s);
-        if (st != RVSEG_OK) return st;
+        // A lattice build that overflows its hash table leaves the chunk's CRF outputs unwritten (every
+        // later kernel exits early).  The status is known after the sync below; the context has then
+        // raised its capacity (x8 per step, up to the worst case) and the chunk is simply run again.
+        for (int attempt = 0;; attempt++) {
+            timer_reset(ctx);
+            if ((st = upload_calib(ctx, im, calib + (size_t)start * 21, n, s)) != RVSEG_OK) return st;
+            st = run_chunk(ctx, im, n, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
+                           im->post.as<float>(), want_marg ? im->marg.as<float>() : nullptr,
+                           labels_out ? im->labels.as<int8_t>() : nullptr, s);
+            if (st == RVSEG_OK) {
+                RV_HIP(ctx, hipStreamSynchronize(s));
+                st = crf_frames_status(ctx, im, true);
+            } else {
+                (void)hipStreamSynchronize(s);
+            }
+            if (st == RVSEG_OK) break;
+            if (st != RVSEG_ERR_CAPACITY || attempt >= 8) return st;
+        }
         if (posteriors_out)
             RV_HIP(ctx, hipMemcpyAsync(posteriors_out + (size_t)start * npix * S, im->post.p, npix * S * 4 * n, hipMemcpyDeviceToHost, s));
         if (want_marg)
@@ -321,6 +346,13 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
         RV_HIP(ctx, hipStreamSynchronize(s));
     }
     return RVSEG_OK;
+}
+
+rvseg_status rvseg_poll_status(rvseg_ctx* ctx, int32_t wait) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!ctx->impl) return RVSEG_OK;
+    RV_HIP(ctx, hipSetDevice(ctx->params.device));
+    return crf_frames_status(ctx, reinterpret_cast<Pipeline*>(ctx->impl), wait != 0);
 }
 
 rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const uint16_t* depth_mm, const float* calib,

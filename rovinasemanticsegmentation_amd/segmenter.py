@@ -61,6 +61,26 @@ class Context:
         else:
             capi.check(self.h, self.L.rvseg_forest_load(self.h, str(src).encode()))
 
+    def forest_write(self, path=None):
+        """RandomForest::write (classifier.cpp:210-220): to `path`, or returns the bytes."""
+        if path is not None:
+            capi.check(self.h, self.L.rvseg_forest_write(self.h, str(path).encode()))
+            return None
+        size = C.c_size_t()
+        capi.check(self.h, self.L.rvseg_forest_write_mem(self.h, None, 0, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        capi.check(self.h, self.L.rvseg_forest_write_mem(self.h, buf, size.value, C.byref(size)))
+        return buf.raw[:size.value]
+
+    def poll_status(self, wait=True):
+        """Status of the asynchronous part of the last segment_frames_device call: capi.OK,
+        capi.NOT_READY (only with wait=False) or raises RvsegError(ERR_CAPACITY)."""
+        st = self.L.rvseg_poll_status(self.h, 1 if wait else 0)
+        if st == capi.NOT_READY:
+            return st
+        capi.check(self.h, st)
+        return st
+
     def forest_info(self):
         nt, nn, md, nl = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         cc = (C.c_int32 * capi.RVSEG_MAX_LAYERS)()
@@ -207,6 +227,9 @@ class RandomForest:
 
     def read(self, src):  # RandomForest::read(std::istream&), classifier.cpp:222
         self.ctx.forest_load(src)
+
+    def write(self, dst=None):  # RandomForest::write(std::ostream&), classifier.cpp:210
+        return self.ctx.forest_write(dst)
 
     def getSize(self):
         return self.ctx.forest_info()["n_trees"]

@@ -67,3 +67,48 @@ def test_cpp_facade_header_compiles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "segmenter_facade_test.cpp")])
+
+
+# ---- host-only forest entry points (no GPU needed): rvseg_forest_check / rvseg_forest_rewrite -------
+def _golden(name):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", name), "rb") as fh:
+        return fh.read()
+
+
+@pytest.mark.parametrize("name", ["forest_multi.dat", "forest_single.dat", "forest_tiny.dat"])
+def test_forest_writer_round_trips_reference_written_files_byte_for_byte(name):
+    """The golden files were written by the reference's own RandomForest::write (oracle/gen_golden.py):
+    parsing them and writing them again must give the same bytes (classifier.cpp:144-152,210-220)."""
+    capi = _lib()
+    blob = _golden(name)
+    assert capi.forest_rewrite(blob) == blob
+
+
+def test_forest_check_accepts_the_goldens_and_reports_their_shape():
+    capi = _lib()
+    st, msg, info = capi.forest_check(_golden("forest_multi.dat"), 366)
+    assert st == capi.OK, msg
+    assert info["n_trees"] >= 1 and info["n_nodes"] > info["n_trees"] and info["max_depth"] >= 1
+
+
+def test_forest_check_refuses_more_than_64_trees():
+    """libforest has no tree limit; the device evaluator keeps 16 leaf rows in each of a point's 4
+    lanes.  A 65-tree ensemble must be refused, not mis-evaluated."""
+    capi = _lib()
+    from rovinasemanticsegmentation_amd import synthetic
+    ok = synthetic.make_forest_bytes(seed=3, n_trees=64, leaves_per_tree=4, max_depth=4)
+    st, msg, info = capi.forest_check(ok, 366)
+    assert st == capi.OK and info["n_trees"] == 64, msg
+    big = synthetic.make_forest_bytes(seed=3, n_trees=65, leaves_per_tree=4, max_depth=4)
+    st, msg, _ = capi.forest_check(big, 366)
+    assert st == capi.ERR_CAPACITY and "65 trees" in msg
+
+
+def test_forest_check_refuses_corrupt_streams_and_model_config_mismatch():
+    capi = _lib()
+    blob = _golden("forest_tiny.dat")
+    assert capi.forest_check(blob[:len(blob) // 2])[0] == capi.ERR_FORMAT       # truncated
+    assert capi.forest_check(b"\x00\x00\x00\x00")[0] == capi.ERR_NO_FOREST       # T = 0
+    st, msg, _ = capi.forest_check(_golden("forest_multi.dat"), 3)               # D = 3: split features out of range
+    assert st == capi.ERR_FORMAT and "mismatch" in msg

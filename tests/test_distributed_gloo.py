@@ -100,3 +100,70 @@ def test_posterior_gather_keeps_the_fusion_order():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def _gatherer_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rovinasemanticsegmentation_amd.distributed import FrameGatherer
+        start, count = shard_frames(n_frames, rank, world)
+        g = FrameGatherer(n_frames, (5,), torch.int32, "cpu")
+        ok = True
+        ptrs = set()
+        for step in range(3):   # the same preallocated buffers serve every step
+            local = (torch.arange(start, start + count).view(-1, 1) * 10 + torch.arange(5).view(1, -1) + 1000 * step).to(torch.int32)
+            fused = g.gather(local)
+            if rank == 0:
+                want = (torch.arange(n_frames).view(-1, 1) * 10 + torch.arange(5).view(1, -1) + 1000 * step).to(torch.int32)
+                ok = ok and bool(torch.equal(fused, want))
+                ptrs.add(fused.data_ptr())
+        if rank == 0:
+            q.put(ok and len(ptrs) == 1)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 6), (3, 8)])
+def test_frame_gatherer_reuses_its_buffers(world, n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_bench_launcher_starts_its_own_ranks_in_rehearsal_mode():
+    """`python bench.py --gpus 2` must itself start two rank processes (the driver's round-1 scaling run
+    found a bench that ignored --gpus).  Rehearsal mode runs the rank protocol on CPU with gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearsal", "--frames", "3",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["world_size_seen"] == 2 and out["gather_ok"] is True and out["rehearsal"] is True
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0
+    assert "--gpus 2 requested" in r.stderr and "GPU(s)" in r.stderr

@@ -1,0 +1,70 @@
+"""BASELINE.json configs[2] -- the headline configuration bench.py times -- checked for correctness on
+the GPU: one chunk of 64 synthetic 640x480 key frames (holes on) through rvseg_segment_frames_device
+with max_batch = 64, RF (bench forest: 4 trees x 2^14 leaves, C = 9) + 5-iteration DenseCRF.
+
+  (a) every frame bit-exact against the CPU oracle (labels, and marginals well inside the north star's
+      1e-4) -- frames 0, 9, 31, 63 sit in different XCD launch groups of the splat (kernels_crf.hip),
+      all 64 are compared; the oracle frames run in a thread pool (ctypes releases the GIL);
+  (b) all 64 frames against single-frame GPU runs of the same context parameters.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from rovinasemanticsegmentation_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+W, H, N_FRAMES, C = 640, 480, 64, 9
+TOL = 1e-4   # BASELINE.json north_star: CRF class marginals within 1e-4, argmax labels bit-exact
+
+
+def test_batch64_headline_config_matches_oracle_and_single_frame_runs(gpu_ctx_factory, oracle):
+    torch = pytest.importorskip("torch")
+    import rovinasemanticsegmentation_amd as rv
+    dev = torch.device("cuda", 0)
+    N = W * H
+    blob = synthetic.make_forest_bytes(seed=7, n_trees=4, leaves_per_tree=1 << 14, max_depth=30,
+                                       single_classes=C, layer_classes=(8, 9))
+    rgb, depth = synthetic.make_batch(N_FRAMES, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(multi_layer=0, use_dense_crf=1, dcrf_iterations=5, label_mode=rv.capi.LABEL_CRF, unknown_label=[8])
+    ctx = gpu_ctx_factory(max_batch=N_FRAMES, **kw)
+    ctx.forest_load(blob)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_marg = torch.zeros((N_FRAMES, C * N), dtype=torch.float32, device=dev)
+    d_lab = torch.full((N_FRAMES, N), -99, dtype=torch.int8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    ctx.segment_frames_device(N_FRAMES, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
+                              d_lab.data_ptr(), stream.cuda_stream)
+    assert ctx.poll_status(wait=True) == rv.capi.OK
+    torch.cuda.synchronize(dev)
+    marg = d_marg.cpu().numpy()
+    lab = d_lab.cpu().numpy()
+    assert (lab != -99).all()
+
+    # (a) the CPU oracle, frame by frame
+    forest = oracle.Forest(blob)
+    p = oracle.default_params(dcrf_iterations=5)
+
+    def one(i):
+        return oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
+
+    with ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, 16))) as ex:
+        want = list(ex.map(one, range(N_FRAMES)))
+    for i in [0, 9, 31, 63] + [k for k in range(N_FRAMES) if k not in (0, 9, 31, 63)]:
+        _, wm, wl = want[i]
+        assert np.array_equal(lab[i], wl), "labels of frame %d differ from the oracle" % i
+        assert np.abs(marg[i] - wm).max() <= TOL, i
+        assert np.array_equal(marg[i], wm), "marginals of frame %d are not bit-identical to the oracle" % i
+
+    # (b) the same frames one at a time on the GPU (chunk of 1: other launch shapes, no XCD groups)
+    one_ctx = gpu_ctx_factory(max_batch=1, **kw)
+    one_ctx.forest_load(blob)
+    for i in range(N_FRAMES):
+        out = one_ctx.segment_frames(rgb[i:i + 1], depth[i:i + 1], calib, want_posteriors=False)
+        assert np.array_equal(out["labels"][0].ravel(), lab[i]), i
+        assert np.array_equal(out["marginals"][0], marg[i]), i
