@@ -186,6 +186,14 @@ rvseg_status rvseg_crf_infer_multi(rvseg_ctx *ctx, int32_t N, int32_t C, int32_t
                                    const float *unary_energy, int32_t iterations, float *Q_out,
                                    int8_t *map_out, int32_t label_mode, int32_t unknown_label);
 
+/* Host-side feature builders of DenseCRF2D (densecrf.cpp:61-81), for rvseg_crf_infer_multi:
+ *   addPairwiseGaussian(sx, sy)                 f = (x / sx, y / sy)                            out: W*H x 2
+ *   addPairwiseBilateral(sx, sy, sr, sg, sb, im) f = (x / sx, y / sy, r / sr, g / sg, b / sb)    out: W*H x 5
+ * im: H x W x 3 uint8 in the channel order of the caller's image.  No context, no GPU. */
+rvseg_status rvseg_crf_features_gaussian(int32_t W, int32_t H, float sx, float sy, float *out);
+rvseg_status rvseg_crf_features_bilateral(int32_t W, int32_t H, float sx, float sy, float sr, float sg, float sb,
+                                          const uint8_t *im, float *out);
+
 /* ---- lattice introspection for parity tests: Permutohedral::init + compute
  *      (densecrf permutohedral.cpp:140-321,596-603).  offsets_out / bary_out: N x (d+1);
  *      keys_out: capacity M_cap x d int16; vertex numbering is arbitrary (results do not depend on
@@ -215,6 +223,40 @@ rvseg_status rvseg_lattice_neighbours(rvseg_ctx *ctx, int32_t *n1_out, int32_t *
 rvseg_status rvseg_fuse_posteriors(rvseg_ctx *ctx, int32_t n_images, const int32_t *index_images,
                                    const float *posteriors, int32_t n_layers, const int32_t *class_counts,
                                    int32_t cloud_size, float *unaries_out);
+
+/* ---- the same consumers with every buffer resident in HBM (device pointers, work enqueued on hip_stream,
+ *      no synchronisation, no allocation per call once the context's buffers have grown): the local-map
+ *      thread can take d_posteriors_out of rvseg_segment_frames_device as it is, instead of moving
+ *      11-21 MB per frame over PCIe twice.  An index >= cloud_size is skipped like "no point" and reported
+ *      by rvseg_poll_status (RVSEG_ERR_INVALID_ARG). */
+rvseg_status rvseg_fuse_posteriors_device(rvseg_ctx *ctx, int32_t n_images, const int32_t *d_index_images,
+                                          const float *d_posteriors, int32_t n_layers, const int32_t *class_counts,
+                                          int32_t cloud_size, float *d_unaries_out, void *hip_stream);
+/* pairwise = (x,y,z) * dcrf_xyz_kernel ++ (r,g,b) * dcrf_rgb_kernel per point, rgb in [0,1]
+ * (src/segmenter.cpp:629-637).  d_features_out: N x 6. */
+rvseg_status rvseg_cloud_features_device(rvseg_ctx *ctx, int32_t N, const float *d_xyz, const float *d_rgb,
+                                         float *d_features_out, void *hip_stream);
+/* DenseCRF call shape of src/segmenter.cpp:641-644 on device buffers, one Potts kernel.  unary_is_energy = 0:
+ * d_unary holds the accumulated log-posteriors and the energy is their negative (crf.setUnaryEnergy(-unaries[l]),
+ * :642) -- no negated copy is made.  d_Q_out or d_map_out may be NULL (not both).  The lattice build reads
+ * its counters back once (one synchronisation of hip_stream) so that a hash overflow is retried here. */
+rvseg_status rvseg_crf_infer_device(rvseg_ctx *ctx, int32_t N, int32_t C, int32_t d, const float *d_unary,
+                                    int32_t unary_is_energy, const float *d_features, float potts_w,
+                                    int32_t iterations, float *d_Q_out, int8_t *d_map_out, int32_t label_mode,
+                                    int32_t unknown_label, void *hip_stream);
+rvseg_status rvseg_label_values_device(rvseg_ctx *ctx, const float *d_values, int32_t N, int32_t C,
+                                       int32_t label_mode, int32_t unknown_label, int8_t *d_labels_out,
+                                       void *hip_stream);
+/* Replaces the body of Segmenter::processMapFromQueue for one local map (src/segmenter.cpp:561-682) with
+ * everything in HBM: fusion through the index images (:561-616), then per label layer of the loaded model
+ * either the cloud DenseCRF + "> 2.0/C else Unknown" (params.use_dense_crf, :628-658; one lattice serves all
+ * layers -- the reference builds the same one per layer) or the no-CRF rule (:660-681).
+ *   d_labels_out   L x cloud_size int8 (result_labels[layer][i], :646-657)
+ *   d_unaries_out  optional: the fused unaries, layers concatenated (else they stay in context memory) */
+rvseg_status rvseg_process_map_device(rvseg_ctx *ctx, int32_t n_images, const int32_t *d_index_images,
+                                      const float *d_posteriors, int32_t cloud_size, const float *d_cloud_xyz,
+                                      const float *d_cloud_rgb, int8_t *d_labels_out, float *d_unaries_out,
+                                      void *hip_stream);
 
 /* One of the label rules above over a host matrix of N points x C classes (class-contiguous); the
  * no-CRF branch of processMapFromQueue applies RVSEG_LABEL_NOCRF to the fused unaries

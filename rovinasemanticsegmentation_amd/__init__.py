@@ -6,7 +6,7 @@ runtime.  There is no CPU fallback: without the built library the import of `_ca
 without a GPU `Context()` raises.
 """
 from . import _capi as capi  # noqa: F401
-from .segmenter import Context, DenseCRF, FeatureExtractor, RandomForest, Segmenter  # noqa: F401
+from .segmenter import Context, DenseCRF, FeatureExtractor, LocalMapStore, RandomForest, Segmenter  # noqa: F401
 from . import synthetic  # noqa: F401
 
-__all__ = ["capi", "Context", "DenseCRF", "FeatureExtractor", "RandomForest", "Segmenter", "synthetic"]
+__all__ = ["capi", "Context", "DenseCRF", "FeatureExtractor", "LocalMapStore", "RandomForest", "Segmenter", "synthetic"]

@@ -24,6 +24,9 @@ SYMBOLS = [
     "rvseg_fuse_posteriors", "rvseg_label_values",
     "rvseg_forest_check", "rvseg_forest_write", "rvseg_forest_write_mem", "rvseg_forest_rewrite",
     "rvseg_poll_status",
+    "rvseg_fuse_posteriors_device", "rvseg_cloud_features_device", "rvseg_crf_infer_device",
+    "rvseg_label_values_device", "rvseg_process_map_device",
+    "rvseg_crf_features_gaussian", "rvseg_crf_features_bilateral",
 ]
 
 
@@ -97,6 +100,13 @@ def lib():
     L.rvseg_forest_write_mem.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rvseg_forest_rewrite.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rvseg_poll_status.argtypes = [vp, i32]
+    L.rvseg_fuse_posteriors_device.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp]
+    L.rvseg_cloud_features_device.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.rvseg_crf_infer_device.argtypes = [vp, i32, i32, i32, vp, i32, vp, f32, i32, vp, vp, i32, i32, vp]
+    L.rvseg_label_values_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    L.rvseg_process_map_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.rvseg_crf_features_gaussian.argtypes = [i32, i32, f32, f32, vp]
+    L.rvseg_crf_features_bilateral.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, vp]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library does not export it
     _lib = L
@@ -143,3 +153,25 @@ def forest_rewrite(blob):
     if st != OK:
         raise RvsegError(st, lib().rvseg_status_string(st).decode())
     return out.raw[:size.value]
+
+
+def crf_features_gaussian(W, H, sx, sy):
+    """DenseCRF2D::addPairwiseGaussian's feature matrix (densecrf.cpp:61-69), W*H x 2, host only."""
+    import numpy as np
+    out = np.empty((W * H, 2), np.float32)
+    st = lib().rvseg_crf_features_gaussian(W, H, sx, sy, out.ctypes.data_as(C.c_void_p))
+    if st != OK:
+        raise RvsegError(st, lib().rvseg_status_string(st).decode())
+    return out
+
+
+def crf_features_bilateral(W, H, sx, sy, sr, sg, sb, im):
+    """DenseCRF2D::addPairwiseBilateral's feature matrix (densecrf.cpp:70-81), W*H x 5, host only."""
+    import numpy as np
+    im = np.ascontiguousarray(im, np.uint8)
+    assert im.size == W * H * 3
+    out = np.empty((W * H, 5), np.float32)
+    st = lib().rvseg_crf_features_bilateral(W, H, sx, sy, sr, sg, sb, im.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    if st != OK:
+        raise RvsegError(st, lib().rvseg_status_string(st).decode())
+    return out

@@ -296,33 +296,42 @@ normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const u
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-tiled variant for stride <= 2: a block owns 8 x 16 sample points; the fixed-point gradients
-// of its pixel tile (+ 6-px apron) are formed once, cooperatively, and the window sums then run
-// entirely out of LDS.  Same integer sums, so the result is identical to the gather kernel.
+// LDS-tiled variant: a block owns 8 x 16 sample points.  The fixed-point gradients of its pixel tile
+// (+ 6-px apron) are formed once, cooperatively, and turned into a two-dimensional prefix sum
+// (summed-area table) IN PLACE: a window sum is then four corner reads per channel instead of up to
+// 10 x 10 cells -- the integral-image evaluation PCL itself uses (feature_extractor.h:256-261), here
+// on exact 2^-32 fixed-point int64 (order free, and exact modulo 2^64 even if a clamped outlier made
+// a partial sum wrap), so the result is identical to the direct window walk of the gather kernel.
+//   table: 7 planes x (th + 1) x (tw + 1) 8-byte cells, row 0 / column 0 are zero;
+//          planes 0..5 = gx0 gx1 gx2 gy0 gy1 gy2, plane 6 = {count_x, count_y} as two int32
 // ---------------------------------------------------------------------------------------------
 constexpr int NF_TY = 8, NF_TX = 16, NF_APRON = 6;
-constexpr int NF_PARTS = 4;   // lanes per sample point: each sums every 4th window row (integer sums: any order)
+constexpr int NF_PARTS = 4;     // lanes per sample point: three take two gradient planes each, one the counts
+constexpr int NF_PLANES = 7;
+constexpr int NF_THREADS = NF_TY * NF_TX * NF_PARTS;
 
-__global__ void __launch_bounds__(NF_TY * NF_TX * NF_PARTS)
+__global__ void __launch_bounds__(NF_THREADS)
 normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const uint8_t* __restrict__ rect_all,
                             float* __restrict__ nfeat_all, int tiles_x, int tiles_y) {
-    extern __shared__ __attribute__((aligned(16))) long long grad[];   // [th*tw][6], then flags
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sat[];   // [NF_PLANES][th + 1][tw + 1]
     const int s = g.stride;
     const int tw = NF_TX * s + 2 * NF_APRON, th = NF_TY * s + 2 * NF_APRON;
-    unsigned char* flags = reinterpret_cast<unsigned char*>(grad + (size_t)th * tw * 6);
+    const int pw = tw + 1, ph = th + 1;           // padded plane: row 0 and column 0 stay zero
+    const int plane = pw * ph;
     const int W = g.W, H = g.H;
     const int frame = blockIdx.x / (tiles_x * tiles_y);
     const int tile = blockIdx.x - frame * tiles_x * tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int px0 = tx * NF_TX * s - NF_APRON, py0 = ty * NF_TY * s - NF_APRON;   // pixel of LDS cell (0,0)
+    const int px0 = tx * NF_TX * s - NF_APRON, py0 = ty * NF_TY * s - NF_APRON;   // pixel of tile cell (0,0)
     const float4* cloud = cloud_all + (size_t)frame * W * H;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < th * tw; idx += NF_TY * NF_TX * NF_PARTS) {
-        const int ly = idx / tw, lx = idx - ly * tw;
-        const int y = py0 + ly, x = px0 + lx;
+    // ---- gradients (PCL: central differences of the organised cloud), one padded cell per thread step
+    for (int idx = tid; idx < plane; idx += NF_THREADS) {
+        const int cy = idx / pw, cx = idx - cy * pw;
         long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
-        unsigned char fl = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
+        unsigned cnt_x = 0, cnt_y = 0;
+        const int y = py0 + cy - 1, x = px0 + cx - 1;
+        if (cy > 0 && cx > 0 && y >= 0 && y < H && x >= 0 && x < W) {
             float dx0 = 0.f, dx1 = 0.f, dx2 = 0.f, dy0 = 0.f, dy1 = 0.f, dy2 = 0.f;
             if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
                 const float4 r = cloud[(size_t)y * W + x + 1], l = cloud[(size_t)y * W + x - 1];
@@ -330,15 +339,35 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
                 dx0 = r.x - l.x; dx1 = r.y - l.y; dx2 = r.z - l.z;
                 dy0 = dn.x - up.x; dy1 = dn.y - up.y; dy2 = dn.z - up.z;
             }
-            if (finite_f(dx0) && finite_f(dx1) && finite_f(dx2)) { fl |= 1; gx0 = to_fix32(dx0); gx1 = to_fix32(dx1); gx2 = to_fix32(dx2); }
-            if (finite_f(dy0) && finite_f(dy1) && finite_f(dy2)) { fl |= 2; gy0 = to_fix32(dy0); gy1 = to_fix32(dy1); gy2 = to_fix32(dy2); }
+            if (finite_f(dx0) && finite_f(dx1) && finite_f(dx2)) { cnt_x = 1; gx0 = to_fix32(dx0); gx1 = to_fix32(dx1); gx2 = to_fix32(dx2); }
+            if (finite_f(dy0) && finite_f(dy1) && finite_f(dy2)) { cnt_y = 1; gy0 = to_fix32(dy0); gy1 = to_fix32(dy1); gy2 = to_fix32(dy2); }
         }
-        long long* d = grad + (size_t)idx * 6;
-        d[0] = gx0; d[1] = gx1; d[2] = gx2; d[3] = gy0; d[4] = gy1; d[5] = gy2;
-        flags[idx] = fl;
+        sat[0 * plane + idx] = (unsigned long long)gx0; sat[1 * plane + idx] = (unsigned long long)gx1;
+        sat[2 * plane + idx] = (unsigned long long)gx2; sat[3 * plane + idx] = (unsigned long long)gy0;
+        sat[4 * plane + idx] = (unsigned long long)gy1; sat[5 * plane + idx] = (unsigned long long)gy2;
+        sat[6 * plane + idx] = (unsigned long long)cnt_x | ((unsigned long long)cnt_y << 32);   // two int32 counters, no carry between them (<= 1232 each)
     }
     __syncthreads();
-    const int sample = tid / NF_PARTS, part = tid - sample * NF_PARTS;   // the NF_PARTS lanes of a sample are adjacent
+    // ---- prefix along x: one thread per (plane, row) walks its row (unsigned: wrap-around is harmless)
+    for (int t = tid; t < NF_PLANES * th; t += NF_THREADS) {
+        const int k = t / th, cy = t - k * th + 1;
+        unsigned long long* row = sat + (size_t)k * plane + (size_t)cy * pw;
+        unsigned long long run = 0;
+#pragma unroll 4
+        for (int cx = 1; cx < pw; cx++) { run += row[cx]; row[cx] = run; }
+    }
+    __syncthreads();
+    // ---- prefix along y: one thread per (plane, column)
+    for (int t = tid; t < NF_PLANES * tw; t += NF_THREADS) {
+        const int k = t / tw, cx = t - k * tw + 1;
+        unsigned long long* col = sat + (size_t)k * plane + cx;
+        unsigned long long run = 0;
+#pragma unroll 4
+        for (int cy = 1; cy < ph; cy++) { run += col[(size_t)cy * pw]; col[(size_t)cy * pw] = run; }
+    }
+    __syncthreads();
+    // ---- window sums: the NF_PARTS lanes of a sample are adjacent; lane `part` fetches two planes
+    const int sample = tid / NF_PARTS, part = tid - sample * NF_PARTS;
     const int sy = sample / NF_TX, sx = sample - sy * NF_TX;
     const int ly_s = ty * NF_TY + sy, lx_s = tx * NF_TX + sx;   // sample grid coordinates
     const bool inside = ly_s < g.lh && lx_s < g.lw;
@@ -350,28 +379,35 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
         const float zc = cloud[(size_t)ri * W + ci].z;
         if (!finite_f(zc)) rect = 0;
     }
-    long long gx0 = 0, gx1 = 0, gx2 = 0, gy0 = 0, gy1 = 0, gy2 = 0;
-    int cnt_x = 0, cnt_y = 0;
+    unsigned long long a = 0, b = 0;     // this lane's two planes (the counter lane: a = {count_x, count_y})
     if (rect > 0) {
         const int rect2 = rect >> 1;
-        const int wx = ci - rect2 - px0, wy = ri - rect2 - py0;   // window origin inside the tile
-        for (int yy = wy + part; yy < wy + rect; yy += NF_PARTS) {
-            for (int xx = wx; xx < wx + rect; xx++) {
-                const int idx = yy * tw + xx;
-                const long long* d = grad + (size_t)idx * 6;
-                const unsigned char fl = flags[idx];
-                cnt_x += fl & 1; cnt_y += (fl >> 1) & 1;
-                gx0 += d[0]; gx1 += d[1]; gx2 += d[2]; gy0 += d[3]; gy1 += d[4]; gy2 += d[5];
-            }
+        // window = tile cells [wx, wx + rect) x [wy, wy + rect)  ->  padded cells +1; corners of the inclusive table
+        const int wx = ci - rect2 - px0, wy = ri - rect2 - py0;
+        const int x0 = wx, x1 = wx + rect, y0 = wy, y1 = wy + rect;     // padded coordinates: sum = S[y1][x1] - S[y0][x1] - S[y1][x0] + S[y0][x0]
+        const int k0 = part < 3 ? 2 * part : 6;
+        const unsigned long long* P = sat + (size_t)k0 * plane;
+        a = P[(size_t)y1 * pw + x1] - P[(size_t)y0 * pw + x1] - P[(size_t)y1 * pw + x0] + P[(size_t)y0 * pw + x0];
+        if (part < 3) {
+            const unsigned long long* Q = P + plane;
+            b = Q[(size_t)y1 * pw + x1] - Q[(size_t)y0 * pw + x1] - Q[(size_t)y1 * pw + x0] + Q[(size_t)y0 * pw + x0];
+        } else {
+            // the two packed int32 counters were subtracted as one 64-bit word: a borrow out of the low
+            // counter's difference (never negative as a true count) cannot occur in the final sum, but
+            // intermediate terms may borrow; recompute each half on its own
+            const unsigned lo = (unsigned)P[(size_t)y1 * pw + x1] - (unsigned)P[(size_t)y0 * pw + x1] - (unsigned)P[(size_t)y1 * pw + x0] + (unsigned)P[(size_t)y0 * pw + x0];
+            const unsigned hi = (unsigned)(P[(size_t)y1 * pw + x1] >> 32) - (unsigned)(P[(size_t)y0 * pw + x1] >> 32) -
+                                (unsigned)(P[(size_t)y1 * pw + x0] >> 32) + (unsigned)(P[(size_t)y0 * pw + x0] >> 32);
+            a = (unsigned long long)lo | ((unsigned long long)hi << 32);
         }
     }
-    // the four partial sums of a sample sit in adjacent lanes of one wave
-#pragma unroll
-    for (int m = 1; m < NF_PARTS; m <<= 1) {
-        gx0 += __shfl_xor(gx0, m, 64); gx1 += __shfl_xor(gx1, m, 64); gx2 += __shfl_xor(gx2, m, 64);
-        gy0 += __shfl_xor(gy0, m, 64); gy1 += __shfl_xor(gy1, m, 64); gy2 += __shfl_xor(gy2, m, 64);
-        cnt_x += __shfl_xor(cnt_x, m, 64); cnt_y += __shfl_xor(cnt_y, m, 64);
-    }
+    // gather the sample's seven sums into its first lane (the four lanes sit in one wave)
+    const int lane = tid & 63, base = lane & ~(NF_PARTS - 1);
+    const long long gx0 = (long long)__shfl(a, base + 0, 64), gx1 = (long long)__shfl(b, base + 0, 64);
+    const long long gx2 = (long long)__shfl(a, base + 1, 64), gy0 = (long long)__shfl(b, base + 1, 64);
+    const long long gy1 = (long long)__shfl(a, base + 2, 64), gy2 = (long long)__shfl(b, base + 2, 64);
+    const unsigned long long cnt = __shfl(a, base + 3, 64);
+    const int cnt_x = (int)(unsigned)cnt, cnt_y = (int)(unsigned)(cnt >> 32);
     if (!inside || part != 0) return;
     float out = -2.0f;
     if (rect > 0 && cnt_x > 0 && cnt_y > 0) {
@@ -408,10 +444,18 @@ void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_cha
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
                            int n, hipStream_t s) {
     const int tw = NF_TX * g.stride + 2 * NF_APRON, th = NF_TY * g.stride + 2 * NF_APRON;
-    const size_t lds = (size_t)tw * th * 49;
-    if (lds <= 64 * 1024) {
+    const size_t lds = (size_t)(tw + 1) * (th + 1) * NF_PLANES * 8;
+    if (lds <= 80 * 1024) {   // stride <= 2 (73 KB: two tiles per CU); larger strides use the gather kernel
+        static bool attr_set[64] = {};   // per device: more than the default 64 KB of dynamic LDS has to be asked for
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(normal_feature_tiled_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
         const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
-        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_TY * NF_TX * NF_PARTS), lds, s>>>(
+        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_THREADS), lds, s>>>(
             g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y);
         return;
     }

@@ -383,6 +383,36 @@ rvseg_status rvseg_forest_eval(rvseg_ctx* ctx, const float* X, int32_t P, int32_
     return rc;
 }
 
+// DenseCRF2D::addPairwiseGaussian / addPairwiseBilateral (densecrf.cpp:61-81): the feature matrices they
+// build, point-major (N x d == the column-major d x N Eigen matrix).  int / float and uchar / float
+// divisions in fp32, exactly the reference's expressions.
+rvseg_status rvseg_crf_features_gaussian(int32_t W, int32_t H, float sx, float sy, float* out) {
+    if (W <= 0 || H <= 0 || !out) return RVSEG_ERR_INVALID_ARG;
+    for (int j = 0; j < H; j++)
+        for (int i = 0; i < W; i++) {
+            float* f = out + ((size_t)j * W + i) * 2;
+            f[0] = i / sx;
+            f[1] = j / sy;
+        }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_crf_features_bilateral(int32_t W, int32_t H, float sx, float sy, float sr, float sg, float sb,
+                                          const uint8_t* im, float* out) {
+    if (W <= 0 || H <= 0 || !im || !out) return RVSEG_ERR_INVALID_ARG;
+    for (int j = 0; j < H; j++)
+        for (int i = 0; i < W; i++) {
+            float* f = out + ((size_t)j * W + i) * 5;
+            const uint8_t* px = im + ((size_t)i + (size_t)j * W) * 3;
+            f[0] = i / sx;
+            f[1] = j / sy;
+            f[2] = px[0] / sr;
+            f[3] = px[1] / sg;
+            f[4] = px[2] / sb;
+        }
+    return RVSEG_OK;
+}
+
 int32_t rvseg_last_timing(const rvseg_ctx* ctx, char* names_out, size_t names_cap, float* ms_out, int32_t max_stages) {
     if (!ctx) return 0;
     const auto& t = ctx->timer;

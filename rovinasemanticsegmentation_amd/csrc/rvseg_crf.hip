@@ -379,6 +379,64 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
     return RVSEG_OK;
 }
 
+// Permutohedral::init on device-resident features with the overflow retry of the host entry points:
+// the counters are read back (one stream synchronisation) before the mean field is enqueued
+static rvseg_status lattice_build_retry(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& lb, int d, int N, const float* d_feat, hipStream_t s) {
+    rvseg_status st;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((st = lattice_prepare(ctx, lb, d, N, 1, attempt == 1)) != RVSEG_OK) return st;
+        FeatureSource fs{};
+        fs.mode = 0; fs.feat = d_feat;
+        if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
+        int cnt[3];
+        if ((st = lattice_counters(ctx, cs, lb, s, cnt)) != RVSEG_OK) return st;
+        if (!cnt[1]) return RVSEG_OK;
+    }
+    ctx->err = "lattice hash table overflow";
+    return RVSEG_ERR_CAPACITY;
+}
+
+static rvseg_status crf_bare_state(rvseg_ctx* ctx, Pipeline** im_out, CrfState** cs_out) {
+    if (!ctx->impl) {
+        Pipeline* im = new Pipeline();
+        ctx->impl = reinterpret_cast<rvseg_ctx::Impl*>(im);
+        im->bare = true;
+    }
+    *im_out = reinterpret_cast<Pipeline*>(ctx->impl);
+    return crf_state(ctx, *im_out, cs_out);
+}
+
+rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* class_counts, const float* d_unaries,
+                              const float* d_features, float potts_w, int iterations, int label_mode, const int* unknown,
+                              int8_t* d_labels, hipStream_t s) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_bare_state(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (cs->lat.size() < 1) cs->lat.resize(1);
+    timer_mark(ctx, "lattice_build", s);
+    if ((st = lattice_build_retry(ctx, cs, cs->lat[0], 6, N, d_features, s)) != RVSEG_OK) return st;
+    int cmax = 0;
+    for (int l = 0; l < n_layers; l++) cmax = std::max(cmax, class_counts[l]);
+    if ((st = dev_reserve(ctx, cs->q, (size_t)N * cmax * 4)) != RVSEG_OK) return st;
+    size_t prefix = 0;
+    for (int l = 0; l < n_layers; l++) {
+        const int C = class_counts[l];
+        ValueView U{const_cast<float*>(d_unaries) + (size_t)N * prefix, (size_t)N * C, 0};
+        ValueView Q{cs->q.as<float>(), (size_t)N * C, 0};
+        MfLabels lab{d_labels ? d_labels + (size_t)l * N : nullptr, label_mode, unknown[l], 1, 0};
+        bool done = false;
+        // crf.setUnaryEnergy(-unaries[l]) (segmenter.cpp:642): the accumulated posteriors ARE -energy
+        if ((st = mean_field(ctx, cs, 1, &potts_w, U, false, C, N, N, iterations, Q, s, d_labels ? &lab : nullptr, &done)) != RVSEG_OK) return st;
+        if (d_labels && !done) {
+            timer_mark(ctx, "labels", s);
+            launch_labels(cs->q.as<float>(), (size_t)N, C, label_mode, unknown[l], d_labels + (size_t)l * N, s);
+        }
+        prefix += C;
+    }
+    RV_HIP(ctx, hipGetLastError());
+    return RVSEG_OK;
+}
+
 }  // namespace rvseg
 
 using namespace rvseg;
@@ -443,6 +501,40 @@ rvseg_status rvseg_crf_infer_multi(rvseg_ctx* ctx, int32_t N, int32_t C, int32_t
         RV_HIP(ctx, hipMemcpyAsync(map_out, cs->labels.p, (size_t)N, hipMemcpyDeviceToHost, s));
     }
     RV_HIP(ctx, hipStreamSynchronize(s));
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_crf_infer_device(rvseg_ctx* ctx, int32_t N, int32_t C, int32_t d, const float* d_unary, int32_t unary_is_energy,
+                                    const float* d_features, float potts_w, int32_t iterations, float* d_Q_out, int8_t* d_map_out,
+                                    int32_t label_mode, int32_t unknown_label, void* hip_stream) {
+    Pipeline* im; CrfState* cs;
+    rvseg_status st = crf_enter(ctx, &im, &cs);
+    if (st != RVSEG_OK) return st;
+    if (N <= 0 || C <= 0 || C > 64 || d < 1 || d > 7 || iterations < 0 || !d_unary || !d_features || (!d_Q_out && !d_map_out) ||
+        label_mode < 0 || label_mode > 3) {
+        ctx->err = "bad arguments";
+        return RVSEG_ERR_INVALID_ARG;
+    }
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (cs->lat.size() < 1) cs->lat.resize(1);
+    timer_reset(ctx);
+    timer_mark(ctx, "lattice_build", s);
+    if ((st = lattice_build_retry(ctx, cs, cs->lat[0], d, N, d_features, s)) != RVSEG_OK) return st;
+    float* q = d_Q_out;
+    if (!q) {
+        if ((st = dev_reserve(ctx, cs->q, (size_t)N * C * 4)) != RVSEG_OK) return st;
+        q = cs->q.as<float>();
+    }
+    ValueView U{const_cast<float*>(d_unary), (size_t)N * C, 0}, Q{q, (size_t)N * C, 0};
+    MfLabels lab{d_map_out, label_mode, unknown_label, 1, 0};
+    bool done = false;
+    if ((st = mean_field(ctx, cs, 1, &potts_w, U, unary_is_energy != 0, C, N, N, iterations, Q, s, d_map_out ? &lab : nullptr, &done)) != RVSEG_OK) return st;
+    if (d_map_out && !done) {
+        timer_mark(ctx, "labels", s);
+        launch_labels(q, (size_t)N, C, label_mode, unknown_label, d_map_out, s);
+    }
+    timer_mark(ctx, "end", s);
+    RV_HIP(ctx, hipGetLastError());
     return RVSEG_OK;
 }
 

@@ -5,10 +5,25 @@
 
 namespace rvseg {
 
-struct CrfState;  // rvseg_crf.hip
+struct CrfState;     // rvseg_crf.hip
+struct FusionState;  // rvseg_fusion.hip
+
+// Host-buffer entry point (rvseg_segment_frames): two slots of pinned staging + device in/out
+// buffers, so that the H2D copy of chunk k+1 and the D2H copy of chunk k-1 run under the compute of
+// chunk k (three streams: in, compute, out).
+struct HostStage {
+    static constexpr int SLOTS = 2;
+    void* h_rgb[SLOTS] = {}; void* h_depth[SLOTS] = {}; void* h_post[SLOTS] = {}; void* h_marg[SLOTS] = {}; void* h_lab[SLOTS] = {};
+    size_t c_rgb[SLOTS] = {}, c_depth[SLOTS] = {}, c_post[SLOTS] = {}, c_marg[SLOTS] = {}, c_lab[SLOTS] = {};
+    DevBuf d_rgb[SLOTS], d_depth[SLOTS], d_post[SLOTS], d_marg[SLOTS], d_lab[SLOTS];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[SLOTS] = {}, ev_done[SLOTS] = {}, ev_out[SLOTS] = {};
+    bool ready = false;
+};
 
 struct Pipeline {
     FrameGeom geom{};
+    HostStage stage;
     DevBuf resize_rows;
     UpsampleTables up;
     // per-chunk device buffers (grow-only, sized for up to max_batch frames)
@@ -26,6 +41,7 @@ struct Pipeline {
     // builds of this context (include/rvseg.h, lattice_capacity_log2)
     int cap_boost = 0;
     CrfState* crf = nullptr;
+    FusionState* fusion = nullptr;
     bool bare = false;  // created by a CRF entry point: frame tables not initialised yet
     // the lattice build depends only on the cloud and the colours, not on the forest: it runs on a
     // side stream beside feature extraction + forest evaluation (fork after prep, join before inference)
@@ -37,8 +53,18 @@ rvseg_status pipeline_init(rvseg_ctx* ctx);
 void timer_reset(rvseg_ctx* ctx);
 void timer_mark(rvseg_ctx* ctx, const char* name, hipStream_t s);
 
+// rvseg_fusion.hip
+void fusion_state_free(Pipeline* im);
+rvseg_status fusion_status(rvseg_ctx* ctx, Pipeline* im, bool wait);   // like crf_frames_status, for the index-range flag
+
 // rvseg_crf.hip
 void crf_state_free(Pipeline* im);
+// DenseCRF on a cloud whose unaries / features live in HBM, for every label layer over ONE lattice:
+// d_unaries = layers concatenated, each N x C_l accumulated log-posteriors (energy = -unary,
+// src/segmenter.cpp:642); labels (optional) L x N; marginals stay in context memory
+rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* class_counts, const float* d_unaries,
+                              const float* d_features, float potts_w, int iterations, int label_mode, const int* unknown,
+                              int8_t* d_labels, hipStream_t s);
 // per-frame, per-layer DenseCRF on the frames of one chunk: unary = -(posteriors), features from
 // the back-projected cloud and the colours
 // part 1 (lattice + normaliser; needs the cloud only) and part 2 (mean field per layer + labels)

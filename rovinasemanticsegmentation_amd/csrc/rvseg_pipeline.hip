@@ -1,9 +1,11 @@
 // Frame pipeline: host orchestration of the per-frame hot path over batches of key frames
 // (replaces the body of Segmenter::processFramesFromQueueInternalRF, src/segmenter.cpp:351-431,
 // and -- with use_dense_crf -- the DenseCRF call shape of src/segmenter.cpp:639-657 per frame).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "rvseg_internal.h"
 #include "rvseg_kernels.h"
@@ -114,7 +116,21 @@ static void pipeline_free(Pipeline* im) {
         if (im->calib_ev[i]) { (void)hipEventSynchronize(im->calib_ev[i]); (void)hipEventDestroy(im->calib_ev[i]); }
         if (im->h_calibA[i]) (void)hipHostFree(im->h_calibA[i]);
     }
+    {
+        HostStage& hs = im->stage;
+        for (int i = 0; i < HostStage::SLOTS; i++) {
+            void* hp[] = {hs.h_rgb[i], hs.h_depth[i], hs.h_post[i], hs.h_marg[i], hs.h_lab[i]};
+            for (void* p : hp) if (p) (void)hipHostFree(p);
+            DevBuf* db[] = {&hs.d_rgb[i], &hs.d_depth[i], &hs.d_post[i], &hs.d_marg[i], &hs.d_lab[i]};
+            for (DevBuf* b : db) dev_free(*b);
+            hipEvent_t ev[] = {hs.ev_in[i], hs.ev_done[i], hs.ev_out[i]};
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        }
+        if (hs.s_in) (void)hipStreamDestroy(hs.s_in);
+        if (hs.s_out) (void)hipStreamDestroy(hs.s_out);
+    }
     crf_state_free(im);
+    fusion_state_free(im);
     if (im->side) (void)hipStreamDestroy(im->side);
     if (im->ev_fork) (void)hipEventDestroy(im->ev_fork);
     if (im->ev_join) (void)hipEventDestroy(im->ev_join);
@@ -294,6 +310,52 @@ rvseg_status rvseg_segment_frames_device(rvseg_ctx* ctx, int32_t n_frames, const
     return RVSEG_OK;
 }
 
+// ---- host-buffer entry: pinned staging ring, copies of neighbouring chunks under the compute ----
+namespace {
+
+// pageable <-> pinned copies; large ones are split over a few host threads (one memcpy stream saturates
+// well below the memory bandwidth of the host)
+void host_copy(void* dst, const void* src, size_t bytes) {
+    const size_t min_part = (size_t)4 << 20;
+    unsigned nt = (unsigned)std::min<size_t>(8, bytes / min_part);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && nt > hw) nt = hw;
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t off = (size_t)t * part;
+        if (off >= bytes) break;
+        const size_t len = std::min(part, bytes - off);
+        th.emplace_back([=] { std::memcpy((char*)dst + off, (const char*)src + off, len); });
+    }
+    for (auto& x : th) x.join();
+}
+
+rvseg_status pinned_reserve(rvseg_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
+    if (cap >= bytes && p) return RVSEG_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    RV_HIP(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return RVSEG_OK;
+}
+
+rvseg_status stage_init(rvseg_ctx* ctx, HostStage& hs) {
+    if (hs.ready) return RVSEG_OK;
+    RV_HIP(ctx, hipStreamCreateWithFlags(&hs.s_in, hipStreamNonBlocking));
+    RV_HIP(ctx, hipStreamCreateWithFlags(&hs.s_out, hipStreamNonBlocking));
+    for (int i = 0; i < HostStage::SLOTS; i++) {
+        RV_HIP(ctx, hipEventCreateWithFlags(&hs.ev_in[i], hipEventDisableTiming));
+        RV_HIP(ctx, hipEventCreateWithFlags(&hs.ev_done[i], hipEventDisableTiming));
+        RV_HIP(ctx, hipEventCreateWithFlags(&hs.ev_out[i], hipEventDisableTiming));
+    }
+    hs.ready = true;
+    return RVSEG_OK;
+}
+
+}  // namespace
+
 rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_t* rgb, const uint16_t* depth_mm,
                                   const float* calib, float* posteriors_out, float* marginals_out, int8_t* labels_out) {
     if (!ctx) return RVSEG_ERR_INVALID_ARG;
@@ -304,46 +366,89 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
     rvseg_status st = pipeline_init(ctx);
     if (st != RVSEG_OK) return st;
     Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    HostStage& hs = im->stage;
+    if ((st = stage_init(ctx, hs)) != RVSEG_OK) return st;
     const FrameGeom& g = im->geom;
     const size_t npix = (size_t)g.W * g.H;
     const size_t S = (size_t)ctx->forest.sum_classes, L = (size_t)ctx->forest.n_layers;
     const bool want_marg = marginals_out && ctx->params.use_dense_crf;
     hipStream_t s = ctx->stream;
-    // stage through HBM in chunks of max_batch frames
-    for (int start = 0; start < n_frames; start += ctx->params.max_batch) {
-        const int n = std::min(ctx->params.max_batch, n_frames - start);
-        if ((st = dev_reserve(ctx, im->in_rgb, npix * 3 * n)) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, im->in_depth, npix * 2 * n)) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, im->post, npix * S * 4 * n)) != RVSEG_OK) return st;
-        if (want_marg && (st = dev_reserve(ctx, im->marg, npix * S * 4 * n)) != RVSEG_OK) return st;
-        if (labels_out && (st = dev_reserve(ctx, im->labels, npix * L * n)) != RVSEG_OK) return st;
-        RV_HIP(ctx, hipMemcpyAsync(im->in_rgb.p, rgb + (size_t)start * npix * 3, npix * 3 * n, hipMemcpyHostToDevice, s));
-        RV_HIP(ctx, hipMemcpyAsync(im->in_depth.p, depth_mm + (size_t)start * npix, npix * 2 * n, hipMemcpyHostToDevice, s));
-        // A lattice build that overflows its hash table leaves the chunk's CRF outputs unwritten (every
-        // later kernel exits early).  The status is known after the sync below; the context has then
-        // raised its capacity (x8 per step, up to the worst case) and the chunk is simply run again.
-        for (int attempt = 0;; attempt++) {
-            timer_reset(ctx);
-            if ((st = upload_calib(ctx, im, calib + (size_t)start * 21, n, s)) != RVSEG_OK) return st;
-            st = run_chunk(ctx, im, n, im->in_rgb.as<uint8_t>(), im->in_depth.as<uint16_t>(), im->calibA.as<float>(),
-                           im->post.as<float>(), want_marg ? im->marg.as<float>() : nullptr,
-                           labels_out ? im->labels.as<int8_t>() : nullptr, s);
-            if (st == RVSEG_OK) {
-                RV_HIP(ctx, hipStreamSynchronize(s));
-                st = crf_frames_status(ctx, im, true);
-            } else {
-                (void)hipStreamSynchronize(s);
-            }
-            if (st == RVSEG_OK) break;
-            if (st != RVSEG_ERR_CAPACITY || attempt >= 8) return st;
+    // chunk size: at most max_batch, and small enough that a call has a few chunks to overlap
+    const int chunk = std::max(1, std::min(ctx->params.max_batch, std::max(8, (n_frames + 3) / 4)));
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    auto chunk_n = [&](int c) { return std::min(chunk, n_frames - c * chunk); };
+
+    // copies the outputs of chunk c from its pinned slot into the caller's buffers (after its D2H has run)
+    auto retire = [&](int c) -> rvseg_status {
+        const int slot = c % HostStage::SLOTS, n = chunk_n(c);
+        const size_t start = (size_t)c * chunk;
+        RV_HIP(ctx, hipEventSynchronize(hs.ev_out[slot]));
+        if (posteriors_out) host_copy(posteriors_out + start * npix * S, hs.h_post[slot], npix * S * 4 * n);
+        if (want_marg) host_copy(marginals_out + start * npix * S, hs.h_marg[slot], npix * S * 4 * n);
+        if (labels_out) host_copy(labels_out + start * npix * L, hs.h_lab[slot], npix * L * n);
+        return RVSEG_OK;
+    };
+    auto drain = [&]() { (void)hipStreamSynchronize(hs.s_in); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(hs.s_out); };
+
+    int retries = 0;
+    for (int c = 0; c <= n_chunks; c++) {
+        if (c == n_chunks) {
+            // all chunks are enqueued: the status of the last build is the only one nobody has looked at yet
+            RV_HIP(ctx, hipStreamSynchronize(s));
+            st = ctx->params.use_dense_crf ? crf_frames_status(ctx, im, true) : RVSEG_OK;
+            if (st == RVSEG_ERR_CAPACITY && retries++ < 16) { drain(); c = n_chunks - 2; continue; }   // redo the last chunk
+            if (st != RVSEG_OK) { drain(); return st; }
+            if ((st = retire(n_chunks - 1)) != RVSEG_OK) { drain(); return st; }
+            break;
         }
-        if (posteriors_out)
-            RV_HIP(ctx, hipMemcpyAsync(posteriors_out + (size_t)start * npix * S, im->post.p, npix * S * 4 * n, hipMemcpyDeviceToHost, s));
-        if (want_marg)
-            RV_HIP(ctx, hipMemcpyAsync(marginals_out + (size_t)start * npix * S, im->marg.p, npix * S * 4 * n, hipMemcpyDeviceToHost, s));
-        if (labels_out)
-            RV_HIP(ctx, hipMemcpyAsync(labels_out + (size_t)start * npix * L, im->labels.p, npix * L * n, hipMemcpyDeviceToHost, s));
-        RV_HIP(ctx, hipStreamSynchronize(s));
+        const int slot = c % HostStage::SLOTS, n = chunk_n(c);
+        const size_t start = (size_t)c * chunk;
+        // staging + device buffers of this slot (grow only; the slot's previous chunk c - 2 has been retired)
+        if ((st = pinned_reserve(ctx, hs.h_rgb[slot], hs.c_rgb[slot], npix * 3 * n)) != RVSEG_OK ||
+            (st = pinned_reserve(ctx, hs.h_depth[slot], hs.c_depth[slot], npix * 2 * n)) != RVSEG_OK ||
+            (st = dev_reserve(ctx, hs.d_rgb[slot], npix * 3 * n)) != RVSEG_OK ||
+            (st = dev_reserve(ctx, hs.d_depth[slot], npix * 2 * n)) != RVSEG_OK) { drain(); return st; }
+        const bool need_post_dev = posteriors_out != nullptr;
+        if (need_post_dev && ((st = pinned_reserve(ctx, hs.h_post[slot], hs.c_post[slot], npix * S * 4 * n)) != RVSEG_OK ||
+                              (st = dev_reserve(ctx, hs.d_post[slot], npix * S * 4 * n)) != RVSEG_OK)) { drain(); return st; }
+        if (want_marg && ((st = pinned_reserve(ctx, hs.h_marg[slot], hs.c_marg[slot], npix * S * 4 * n)) != RVSEG_OK ||
+                          (st = dev_reserve(ctx, hs.d_marg[slot], npix * S * 4 * n)) != RVSEG_OK)) { drain(); return st; }
+        if (labels_out && ((st = pinned_reserve(ctx, hs.h_lab[slot], hs.c_lab[slot], npix * L * n)) != RVSEG_OK ||
+                           (st = dev_reserve(ctx, hs.d_lab[slot], npix * L * n)) != RVSEG_OK)) { drain(); return st; }
+        // 1. caller's pageable buffers -> pinned (host threads; the GPU is busy with chunk c - 1 meanwhile)
+        host_copy(hs.h_rgb[slot], rgb + start * npix * 3, npix * 3 * n);
+        host_copy(hs.h_depth[slot], depth_mm + start * npix, npix * 2 * n);
+        // 2. H2D on the input stream, after the compute of chunk c - 2 (the last reader of these device buffers)
+        if (c >= HostStage::SLOTS) RV_HIP(ctx, hipStreamWaitEvent(hs.s_in, hs.ev_done[slot], 0));
+        RV_HIP(ctx, hipMemcpyAsync(hs.d_rgb[slot].p, hs.h_rgb[slot], npix * 3 * n, hipMemcpyHostToDevice, hs.s_in));
+        RV_HIP(ctx, hipMemcpyAsync(hs.d_depth[slot].p, hs.h_depth[slot], npix * 2 * n, hipMemcpyHostToDevice, hs.s_in));
+        RV_HIP(ctx, hipEventRecord(hs.ev_in[slot], hs.s_in));
+        // 3. compute: after its inputs arrived and after the D2H of chunk c - 2 released the output buffers
+        RV_HIP(ctx, hipStreamWaitEvent(s, hs.ev_in[slot], 0));
+        if (c >= HostStage::SLOTS) RV_HIP(ctx, hipStreamWaitEvent(s, hs.ev_out[slot], 0));
+        timer_reset(ctx);
+        if ((st = upload_calib(ctx, im, calib + start * 21, n, s)) != RVSEG_OK) { drain(); return st; }
+        st = run_chunk(ctx, im, n, hs.d_rgb[slot].as<uint8_t>(), hs.d_depth[slot].as<uint16_t>(), im->calibA.as<float>(),
+                       need_post_dev ? hs.d_post[slot].as<float>() : nullptr, want_marg ? hs.d_marg[slot].as<float>() : nullptr,
+                       labels_out ? hs.d_lab[slot].as<int8_t>() : nullptr, s);
+        if (st == RVSEG_ERR_CAPACITY && retries++ < 16) {
+            // the lattice build of chunk c - 1 overflowed its hash table (its status is read at the start of this
+            // chunk's build): nothing of chunk c has been enqueued past the feature branch.  The context has raised
+            // its capacity; take the two chunks again.
+            drain();
+            c = std::max(0, c - 1) - 1;
+            continue;
+        }
+        if (st != RVSEG_OK) { drain(); return st; }
+        RV_HIP(ctx, hipEventRecord(hs.ev_done[slot], s));
+        // 4. D2H on the output stream
+        RV_HIP(ctx, hipStreamWaitEvent(hs.s_out, hs.ev_done[slot], 0));
+        if (posteriors_out) RV_HIP(ctx, hipMemcpyAsync(hs.h_post[slot], hs.d_post[slot].p, npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
+        if (want_marg) RV_HIP(ctx, hipMemcpyAsync(hs.h_marg[slot], hs.d_marg[slot].p, npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
+        if (labels_out) RV_HIP(ctx, hipMemcpyAsync(hs.h_lab[slot], hs.d_lab[slot].p, npix * L * n, hipMemcpyDeviceToHost, hs.s_out));
+        RV_HIP(ctx, hipEventRecord(hs.ev_out[slot], hs.s_out));
+        // 5. hand chunk c - 1 to the caller while chunk c runs (its build status was checked by run_chunk above)
+        if (c >= 1 && (st = retire(c - 1)) != RVSEG_OK) { drain(); return st; }
     }
     return RVSEG_OK;
 }
@@ -352,7 +457,10 @@ rvseg_status rvseg_poll_status(rvseg_ctx* ctx, int32_t wait) {
     if (!ctx) return RVSEG_ERR_INVALID_ARG;
     if (!ctx->impl) return RVSEG_OK;
     RV_HIP(ctx, hipSetDevice(ctx->params.device));
-    return crf_frames_status(ctx, reinterpret_cast<Pipeline*>(ctx->impl), wait != 0);
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    const rvseg_status a = crf_frames_status(ctx, im, wait != 0);
+    if (a != RVSEG_OK) return a;
+    return fusion_status(ctx, im, wait != 0);
 }
 
 rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const uint16_t* depth_mm, const float* calib,

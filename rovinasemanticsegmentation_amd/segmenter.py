@@ -175,6 +175,20 @@ class Context:
         capi.check(self.h, self.L.rvseg_fuse_posteriors(self.h, n, _ptr(idx), _ptr(post), len(class_counts), cc, cloud_size, _ptr(out)))
         return out
 
+    def process_map_device(self, n_images, d_index_images, d_posteriors, cloud_size, d_cloud_xyz, d_cloud_rgb, d_labels,
+                           d_unaries=0, stream=0):
+        """rvseg_process_map_device: integer device addresses, enqueues only."""
+        capi.check(self.h, self.L.rvseg_process_map_device(
+            self.h, n_images, C.c_void_p(d_index_images), C.c_void_p(d_posteriors), cloud_size,
+            C.c_void_p(d_cloud_xyz or None), C.c_void_p(d_cloud_rgb or None), C.c_void_p(d_labels),
+            C.c_void_p(d_unaries or None), C.c_void_p(stream or None)))
+
+    def crf_infer_device(self, N, Cn, d, d_unary, unary_is_energy, d_features, potts_w, iterations, d_Q=0, d_map=0,
+                         label_mode=capi.LABEL_ARGMAX, unknown_label=0, stream=0):
+        capi.check(self.h, self.L.rvseg_crf_infer_device(
+            self.h, N, Cn, d, C.c_void_p(d_unary), 1 if unary_is_energy else 0, C.c_void_p(d_features), C.c_float(potts_w),
+            iterations, C.c_void_p(d_Q or None), C.c_void_p(d_map or None), label_mode, unknown_label, C.c_void_p(stream or None)))
+
     def label_values(self, values, label_mode, unknown_label=0):
         V = np.ascontiguousarray(values, np.float32)
         N, Cn = V.shape
@@ -272,17 +286,11 @@ class DenseCRF:
         assert features.shape[0] == self.N  # assert(features.cols() == N_), densecrf.cpp:55
         self.kernels.append((features, float(potts_weight)))
 
-    def addPairwiseGaussian(self, W, H, sx, sy, w):  # densecrf.cpp:61-69
-        ys, xs = np.mgrid[0:H, 0:W]
-        f = np.stack([xs.ravel().astype(np.float32) / np.float32(sx), ys.ravel().astype(np.float32) / np.float32(sy)], 1)
-        self.addPairwiseEnergy(f, w)
+    def addPairwiseGaussian(self, W, H, sx, sy, w):  # densecrf.cpp:61-69 (features built by the C ABI)
+        self.addPairwiseEnergy(capi.crf_features_gaussian(W, H, sx, sy), w)
 
     def addPairwiseBilateral(self, W, H, sx, sy, sr, sg, sb, im, w):  # densecrf.cpp:70-81
-        ys, xs = np.mgrid[0:H, 0:W]
-        im = np.asarray(im, np.uint8).reshape(H * W, 3).astype(np.float32)
-        f = np.stack([xs.ravel().astype(np.float32) / np.float32(sx), ys.ravel().astype(np.float32) / np.float32(sy),
-                      im[:, 0] / np.float32(sr), im[:, 1] / np.float32(sg), im[:, 2] / np.float32(sb)], 1)
-        self.addPairwiseEnergy(f, w)
+        self.addPairwiseEnergy(capi.crf_features_bilateral(W, H, sx, sy, sr, sg, sb, im), w)
 
     def inference(self, n_iterations, label_mode=capi.LABEL_ARGMAX, unknown_label=0):  # densecrf.cpp:115-131
         U = self.unary if self.unary is not None else np.zeros((self.N, self.M), np.float32)
@@ -295,27 +303,71 @@ class DenseCRF:
         return self.inference(n_iterations, capi.LABEL_ARGMAX)[1]
 
 
+class LocalMapStore:
+    """_cloud_results plus the two services that read it (src/segmenter.cpp:711-774): (map id,
+    result_labels[layer]) pairs in arrival order.  Host only."""
+
+    def __init__(self, layer_names):
+        self.layer_names = list(layer_names)
+        self.results = []
+
+    def store(self, local_map_id, result_labels):  # :711-713
+        self.results.append((int(local_map_id), [np.asarray(l, np.uint8).copy() for l in result_labels]))
+
+    def srvStoredSemanticsIds(self):  # :722-729 -> IdsSrv response `int32[] local_map_ids`
+        return [m[0] for m in self.results]
+
+    def srvGetLocalMapSegmentation(self, local_map_id, segmentation_layers):
+        """:731-774 -> (local_map_id, uint8[] point_labels = requested layers concatenated) or False for an
+        unknown layer name (:744-746) or map id (:773)."""
+        idx = []
+        for name in segmentation_layers:
+            if name in self.layer_names:
+                idx.append(self.layer_names.index(name))
+        if len(idx) != len(segmentation_layers):
+            return False
+        for mid, labels in self.results:
+            if mid == local_map_id:
+                parts = [labels[l] for l in idx]
+                return mid, (np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+        return False
+
+
 class Segmenter:
     """The per-frame inference part of `class Segmenter` (include/segmenter.h:47-69), ROS-free:
     construction loads the forest like Segmenter::Segmenter (src/segmenter.cpp:106-129),
     processFrames does what processFramesFromQueueInternalRF does per dequeued frame
-    (src/segmenter.cpp:351-431) for a whole batch, plus the per-frame DenseCRF when enabled."""
+    (src/segmenter.cpp:351-431) for a whole batch, plus the per-frame DenseCRF when enabled;
+    processMap is processMapFromQueue for one local map; the srv* methods are the three services
+    (:722-792) over plain Python values.
 
-    def __init__(self, forest, **params):
+    layers (optional): [{"name": str, "classes": [(class name, (r, g, b)), ...]}, ...] -- the
+    `color_codings` of config.json (:73-98); needed only by the services and the cloud dumps."""
+
+    def __init__(self, forest, layers=None, **params):
         self.ctx = Context(**params)
         self.ctx.forest_load(forest)
         info = self.ctx.forest_info()
         self.layer_class_counts = info["class_counts"]
         self.layer_count = len(self.layer_class_counts)
+        if layers is None:
+            layers = [{"name": "layer%d" % l, "classes": [("class%d" % c, (0, 0, 0)) for c in range(n)]}
+                      for l, n in enumerate(self.layer_class_counts)]
+        if [len(l["classes"]) for l in layers] != list(self.layer_class_counts):
+            self.ctx.close()
+            raise RuntimeError("model / config mismatch: layer or class counts (README.md:30 of the reference)")
+        self.layers = layers
+        self.store = LocalMapStore([l["name"] for l in layers])
 
     def processFrames(self, color, depth, calib, **kw):
         return self.ctx.segment_frames(color, depth, calib, **kw)
 
-    def processMap(self, index_images, posteriors, cloud_xyz, cloud_rgb, unknown_labels=None):
+    def processMap(self, index_images, posteriors, cloud_xyz, cloud_rgb, unknown_labels=None, local_map_id=None):
         """The body of processMapFromQueue for one local map (src/segmenter.cpp:561-682): fuse the frames'
         label distributions into per-point unaries through the index images, then per layer either the
         cloud DenseCRF with the thresholded argmax (:628-658) or the no-CRF rule (:660-681).
-        cloud_rgb is in [0, 1] like fps_mapper's cloud (:698-700).  Returns (result_labels, unaries)."""
+        cloud_rgb is in [0, 1] like fps_mapper's cloud (:698-700).  With local_map_id the labels are kept
+        for the services (:711-713).  Returns (result_labels, unaries)."""
         p = self.ctx.params
         cc = self.layer_class_counts
         cloud_xyz = np.ascontiguousarray(cloud_xyz, np.float32)
@@ -334,7 +386,22 @@ class Segmenter:
         else:
             for l in range(len(cc)):
                 labels.append(self.ctx.label_values(unaries[l], capi.LABEL_NOCRF, unknown[l]).astype(np.uint8))
+        if local_map_id is not None:
+            self.store.store(local_map_id, labels)
         return labels, unaries
+
+    # ---- services (ROS request / response fields as plain values) -----------------------------------
+    def srvStoredSemanticsIds(self):
+        return self.store.srvStoredSemanticsIds()
+
+    def srvGetLocalMapSegmentation(self, local_map_id, segmentation_layers):
+        return self.store.srvGetLocalMapSegmentation(local_map_id, segmentation_layers)
+
+    def srvSegmentationInformation(self):  # :776-791
+        return {"layer_names": [l["name"] for l in self.layers],
+                "class_counts": [len(l["classes"]) for l in self.layers],
+                "class_names": [c[0] for l in self.layers for c in l["classes"]],
+                "class_colors": [int(v) for l in self.layers for c in l["classes"] for v in c[1]]}
 
     def close(self):
         self.ctx.close()

@@ -95,6 +95,19 @@ int main(int argc, char** argv) {
         std::memcpy(two.data() + post[0].size(), post[0].data(), post[0].size() * 4);
         auto unaries = seg.fusePosteriors(2, index_images.data(), two.data(), N);
         auto fused_labels = seg.processMap(2, index_images.data(), two.data(), N, nullptr, nullptr);   // conf.use_dense_crf == false
+        // the same map again under an id: kept for the services (segmenter.cpp:711-774)
+        auto stored = seg.processMap(5, 2, index_images.data(), two.data(), N, nullptr, nullptr);
+        rvseg::IdsSrvResponse ids;
+        rvseg::LocalMapSegmentationRequest req;
+        rvseg::LocalMapSegmentationResponse resp;
+        req.local_map_id = 5;
+        req.segmentation_layers = {"object", "material"};
+        if (!seg.srvStoredSemanticsIds(ids) || ids.local_map_ids != std::vector<int32_t>{5}) return 1;
+        if (!seg.srvGetLocalMapSegmentation(req, resp) || resp.local_map_id != 5 || resp.point_labels.size() != 2 * N) return 1;
+        if (std::memcmp(resp.point_labels.data(), fused_labels[1].data(), N) != 0 || std::memcmp(resp.point_labels.data() + N, fused_labels[0].data(), N) != 0) return 1;
+        if (stored != fused_labels) return 1;
+        req.local_map_id = 6;
+        if (seg.srvGetLocalMapSegmentation(req, resp)) return 1;
         for (size_t l = 0; l < 2; l++) std::fwrite(unaries[l].data(), 4, unaries[l].size(), out);
         for (size_t l = 0; l < 2; l++) std::fwrite(fused_labels[l].data(), 1, fused_labels[l].size(), out);
         std::fclose(out);

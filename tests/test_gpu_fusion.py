@@ -1,5 +1,7 @@
 """GPU: local-map fusion and cloud labelling (src/segmenter.cpp:561-682)
 through the C ABI against the oracle.  Bit-exact: the sums are fp32 in a fixed order."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -63,3 +65,72 @@ def test_process_map_matches_oracle(gpu_ctx_factory, oracle):
     seen = np.zeros(xyz.shape[0], bool)
     seen[idx[idx >= 0]] = True
     assert (~seen).sum() == 0 or np.all(labels[0][~seen] == 7)
+
+
+@pytest.mark.parametrize("use_crf", [0, 1])
+def test_process_map_device_resident(gpu_ctx_factory, oracle, use_crf):
+    """rvseg_process_map_device: the frames' posteriors never leave HBM -- the frame context writes them with
+    rvseg_segment_frames_device, the map context fuses them through device-resident index images and labels the
+    cloud (CRF branch :628-658 or no-CRF branch :660-681).  Bit-exact against the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    blob = synthetic.make_forest_bytes(seed=5, n_trees=4, leaves_per_tree=512, max_depth=16)
+    forest = oracle.Forest(blob)
+    rgb, depth, calib, xyz, crgb, idx = synthetic.make_local_map(3)
+    n, N, P = 3, 640 * 480, xyz.shape[0]
+    frames = gpu_ctx_factory(multi_layer=1, use_dense_crf=0, max_batch=4)
+    frames.forest_load(blob)
+    cc = frames.forest_info()["class_counts"]
+    S = sum(cc)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_post = torch.empty((n, S * N), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    frames.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, d_post.data_ptr(), 0, 0, s)
+    cmap = gpu_ctx_factory(multi_layer=1, use_dense_crf=use_crf, dcrf_iterations=3, unknown_label=[7, 8])
+    cmap.forest_load(blob)
+    d_idx = torch.from_numpy(idx).to(dev)
+    d_xyz = torch.from_numpy(xyz).to(dev)
+    d_crgb = torch.from_numpy(crgb).to(dev)
+    d_lab = torch.full((len(cc), P), -99, dtype=torch.int8, device=dev)
+    d_un = torch.empty(P * S, dtype=torch.float32, device=dev)
+    for _ in range(2):   # the second call runs on the context's grown buffers
+        cmap.process_map_device(n, d_idx.data_ptr(), d_post.data_ptr(), P, d_xyz.data_ptr(), d_crgb.data_ptr(), d_lab.data_ptr(),
+                                d_un.data_ptr(), s)
+    assert cmap.poll_status(wait=True) == rv.capi.OK
+    torch.cuda.synchronize(dev)
+    post = d_post.cpu().numpy()
+    want_un = oracle.fuse_posteriors(idx, post, cc, P)
+    assert np.array_equal(d_un.cpu().numpy(), want_un)
+    lab = d_lab.cpu().numpy()
+    pairwise = np.concatenate([xyz * np.float32(0.5), crgb * np.float32(4.0)], 1)
+    off = 0
+    for l, c in enumerate(cc):
+        U = want_un[off:off + c * P].reshape(P, c)
+        off += c * P
+        if use_crf:
+            wl = oracle.labels(oracle.crf_inference(-U, pairwise, 10.0, 3), c, 1, [7, 8][l])
+        else:
+            wl = oracle.labels(U, c, 2, [7, 8][l])
+        assert np.array_equal(lab[l], wl), (use_crf, l)
+    names = cmap.last_timing()
+    assert "fusion" in names and (not use_crf or "splat" in names)
+
+
+def test_device_fusion_reports_bad_indices_through_poll_status(gpu_ctx_factory):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    ctx = gpu_ctx_factory(width=160, height=120)
+    idx = np.full((1, 120, 160), -1, np.int32)
+    idx[0, 2, 2] = 9                                           # cloud_size is 7
+    d_idx = torch.from_numpy(idx).to(dev)
+    d_post = torch.ones((1, 4 * 160 * 120), dtype=torch.float32, device=dev)
+    d_un = torch.empty(28, dtype=torch.float32, device=dev)
+    cc = (C.c_int32 * 1)(4)
+    st = ctx.L.rvseg_fuse_posteriors_device(ctx.h, 1, C.c_void_p(d_idx.data_ptr()), C.c_void_p(d_post.data_ptr()), 1, cc, 7,
+                                            C.c_void_p(d_un.data_ptr()), None)
+    assert st == rv.capi.OK
+    with pytest.raises(rv.capi.RvsegError) as e:
+        ctx.poll_status(wait=True)
+    assert e.value.status == rv.capi.ERR_INVALID_ARG
+    assert np.array_equal(d_un.cpu().numpy(), np.zeros(28, np.float32))   # the bad index was skipped like "no point"
