@@ -17,6 +17,7 @@
 //     index.  To stay bit-exact the splat is a GATHER: entries are stably sorted by vertex and each
 //     (vertex, class) chain adds its contributions in ascending point order.  No float atomics.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <string.h>
@@ -757,10 +758,19 @@ template <int CC> struct SplatGroup { static constexpr int G = 64 / CC > 8 ? 8 :
 constexpr int SPLAT_RE = 16, SPLAT_RR = 8;   // the stage list in the kernel is written out for RE == 16; RR must divide RE
 static_assert(SPLAT_RE % SPLAT_RR == 0, "ring positions are compile-time: the row ring has to divide the entry ring");
 
-template <int MODE, int CC, bool FULL>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
-__global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64)
+// GV = vertices per block (<= G).  With GV = G the block is G producer waves + the adder as the last wave.  A block
+// with fewer vertices (GV = 6 for C = 9: 7 waves) puts the adder at wave 3: a workgroup's waves go to the four SIMDs
+// in cyclic order (MI355X_MICROARCH.md, LDS section), so waves w and w + 4 share a SIMD and wave 3 of a 7-wave block
+// has one to itself -- its 64 dependent adds per step no longer compete with a producer for issue slots.  That
+// shortens a step (the critical path of launches with few, long chains: a single frame, a 1280x960 chunk, a cloud)
+// at the price of 7/6 as many block-steps; chunks with many frames are bandwidth bound and keep GV = G.
+// FAST: the input is this library's own Q * norm (finite, >= 0) in one contiguous [point][C] matrix: a padding lane's
+// product is 0 * x = +0 by itself (no select), and the row address needs no per-frame split.
+template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
+__global__ void __launch_bounds__((GV + 1) * 64)
 splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int band) {
-    constexpr int G = SplatGroup<CC>::G;
+    constexpr int G = GV;
+    constexpr int AW = (GV < SplatGroup<CC>::G && GV >= 4) ? 3 : GV;   // the adder's wave index
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
     const int lane = threadIdx.x & 63;
@@ -778,7 +788,8 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
     const int fs1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
     const unsigned n_vert = (unsigned)(fs1 - fs0), gstart = (unsigned)fs0;
     if (r * G >= n_vert) return;
-    const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
+    const bool contig = FAST || (src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0);
+    const int pw = wave < AW ? wave : wave - 1;   // producer index of this wave (unused by the adder)
     {
         // every wave reads the group's G list ranges itself (uniform): no broadcast step
         unsigned n_steps = 0, my_k0 = 0, my_k1 = 0;
@@ -797,15 +808,15 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
                 }
                 const unsigned nt = (k1 - k0 + 63u) / 64u;
                 n_steps = nt > n_steps ? nt : n_steps;
-                if (i == wave) { my_k0 = k0; my_k1 = k1; }
+                if (i == pw && wave != AW) { my_k0 = k0; my_k1 = k1; }
             }
         }
         // the adder's 64 dependent adds are the critical path of every step: it wins issue arbitration
         // against the producers (which run a tile ahead and have slack)
-        if (wave == G) __builtin_amdgcn_s_setprio(3);
+        if (wave == AW) __builtin_amdgcn_s_setprio(3);
         else if (n_steps > 256u) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
-        if (wave < G) {
+        if (wave != AW) {
             // ---- producer of vertex `wave`: barriers 0 .. n_steps - 1 close its tiles, one more ends the item
             const bool has = my_k1 > my_k0;
             const unsigned kc0 = has ? my_k0 : 0u, kc1 = has ? my_k1 : 1u;   // clamp range of the loads (entry 0 exists)
@@ -848,13 +859,14 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
                 const unsigned base = my_k0 + t * 64u;
                 const unsigned n_valid = t < n_tiles ? (my_k1 - base < 64u ? my_k1 - base : 64u) : 0u;
                 const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
-                float (*pb)[68] = prod[t & 1u][wave];
+                float (*pb)[68] = prod[t & 1u][pw];
 #pragma unroll
                 for (int c = 0; c < CC; c++) {
                     float xin = MODE == 2 ? 1.0f : x[s % SPLAT_RR][c];
                     if (MODE == 1) xin = xin * nrm[s];
                     const float pr = wl * xin;
-                    pb[c][lane] = (unsigned)lane < n_valid ? pr : 0.0f;   // +0 past the list: identity of the sum
+                    // +0 past the list: identity of the sum (FAST: wl is 0 there and the row is finite, so pr is +0 already)
+                    pb[c][lane] = (FAST || (unsigned)lane < n_valid) ? pr : 0.0f;
                 }
                 load_entries(t + SPLAT_RE - 1, (s + SPLAT_RE - 1) % SPLAT_RE);
                 gather_rows((s + SPLAT_RR - 1) % SPLAT_RE, (s + SPLAT_RR - 1) % SPLAT_RR);
@@ -891,18 +903,23 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
     }
 }
 
-template <int MODE, int CC>
-static void splat_group_launch(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
-    constexpr int G = SplatGroup<CC>::G;
+template <int MODE, int CC, int GV, bool FAST>
+static void splat_group_launch_g(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
+    constexpr int G = GV;
     // items per XCD group: (frames of the group) x (groups of G vertices a frame can have at most)
     const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned per_group = nfg * (unsigned)((max_mf + G - 1) / G);
     const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
     for (int band = 0; band < L.n_bands; band++) {
-        if (n == CC) splat_group_kernel<MODE, CC, true><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
-        else splat_group_kernel<MODE, CC, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
+        if (n == CC) splat_group_kernel<MODE, CC, true, GV, FAST><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
+        else splat_group_kernel<MODE, CC, false, GV, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
     }
+}
+
+template <int MODE, int CC>
+static void splat_group_launch(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
+    splat_group_launch_g<MODE, CC, SplatGroup<CC>::G, false>(L, src, C, c0, n, values, s);
 }
 
 template <int MODE>
@@ -915,9 +932,32 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
     else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
 }
 
-void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s) {
+// RVSEG_SPLAT_GV (timing experiments): 0 = choose by the chunk's shape (default), 6 / 7 = force for C = 8, 9
+static int splat_gv_choice(const LatticeDev& L) {
+    static const int forced = std::getenv("RVSEG_SPLAT_GV") ? std::atoi(std::getenv("RVSEG_SPLAT_GV")) : 0;
+    if (forced == 6 || forced == 7) return forced;
+    // few frames: the launch waits for its longest chains (steps x step time), so the shorter step wins;
+    // many frames: the launch is bound by the bytes it moves, the block count only adds overhead
+    return L.n_frames <= 16 ? 6 : 7;
+}
+
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q) {
     if (mode == 2) {
         splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
+        return;
+    }
+    const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
+    if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8)) {
+        // the mean-field loop's own input (Q * norm written by the previous update): the fast producer, and the
+        // block shape chosen for the chunk
+        const int gv = splat_gv_choice(L);
+        if (C == 9) {
+            if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L, src, C, 0, 9, values, s);
+            else splat_group_launch_g<0, 9, 7, true>(L, src, C, 0, 9, values, s);
+        } else {
+            if (gv == 6) splat_group_launch_g<0, 8, 6, true>(L, src, C, 0, 8, values, s);
+            else splat_group_launch_g<0, 8, 8, true>(L, src, C, 0, 8, values, s);
+        }
         return;
     }
     for (int c0 = 0; c0 < C; c0 += 16) {

@@ -87,7 +87,8 @@ size_t csr_fast_bytes(const LatticeDev& L);
 int csr_pix_per_block();
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
-void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s);
+// own_q: src is the mean-field loop's own Q * norm (finite, non-negative): enables the select-free producer
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q = false);
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks = false);
 // out_mode 0: plain, 1: normaliser, 2: inference update (tmp -= (-w) * (sliced * norm))
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,

@@ -23,7 +23,10 @@ struct LatticeBufs {
 
 struct CrfState {
     std::vector<LatticeBufs> lat;  // one per pairwise kernel
-    DevBuf val_a, val_b, tmp, q, unary, feat, labels;
+    // slot 1 of the scratch buffers: a second label layer's mean field runs beside the first on its own stream
+    DevBuf val_a, val_b, tmp, q, qn, unary, feat, labels, val_a2, val_b2, tmp2, qn2;
+    hipStream_t layer_stream = nullptr;       // the second layer's stream
+    hipEvent_t layer_fork = nullptr, layer_join = nullptr;
     int* h_counters = nullptr;     // pinned: [0] M, [1] overflow, [2] filled of the last build
     hipEvent_t counters_ev = nullptr;
     bool counters_pending = false;
@@ -55,7 +58,11 @@ static void lattice_free(LatticeBufs& b) {
 void crf_state_free(Pipeline* im) {
     if (!im->crf) return;
     for (auto& l : im->crf->lat) lattice_free(l);
-    DevBuf* all[] = {&im->crf->val_a, &im->crf->val_b, &im->crf->tmp, &im->crf->q, &im->crf->unary, &im->crf->feat, &im->crf->labels};
+    DevBuf* all[] = {&im->crf->val_a, &im->crf->val_b, &im->crf->tmp, &im->crf->q, &im->crf->qn, &im->crf->unary, &im->crf->feat, &im->crf->labels,
+                     &im->crf->val_a2, &im->crf->val_b2, &im->crf->tmp2, &im->crf->qn2};
+    if (im->crf->layer_stream) (void)hipStreamDestroy(im->crf->layer_stream);
+    if (im->crf->layer_fork) (void)hipEventDestroy(im->crf->layer_fork);
+    if (im->crf->layer_join) (void)hipEventDestroy(im->crf->layer_join);
     for (DevBuf* x : all) dev_free(*x);
     if (im->crf->h_counters) (void)hipHostFree(im->crf->h_counters);
     if (im->crf->counters_ev) (void)hipEventDestroy(im->crf->counters_ev);
@@ -168,10 +175,10 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     return RVSEG_OK;
 }
 
-static rvseg_status values_reserve(rvseg_ctx* ctx, CrfState* cs, long long m_bound, int C) {
+static rvseg_status values_reserve(rvseg_ctx* ctx, CrfState* cs, long long m_bound, int C, int slot = 0) {
     rvseg_status st;
-    if ((st = dev_reserve(ctx, cs->val_a, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
-    if ((st = dev_reserve(ctx, cs->val_b, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, slot ? cs->val_a2 : cs->val_a, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
+    if ((st = dev_reserve(ctx, slot ? cs->val_b2 : cs->val_b, (size_t)m_bound * C * 4)) != RVSEG_OK) return st;
     return RVSEG_OK;
 }
 
@@ -227,22 +234,39 @@ static void filter_into(rvseg_ctx* ctx, const LatticeBufs& b, CrfState* cs, cons
 
 // DenseCRF::inference (densecrf.cpp:115-131)
 // `lab` (optional): where the last fused update may write the labels; *labels_done tells whether it did
+// slot: which set of scratch buffers (0 / 1; two layers may run side by side on two streams);
+// timed: record stage marks (only one of two concurrent loops may: the marks are a sequence on ONE stream)
 static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, const float* ws, const ValueView& unary,
                                bool unary_is_energy, int C, int N, long long n_points, int iterations,
-                               const ValueView& Q, hipStream_t s, const MfLabels* lab = nullptr, bool* labels_done = nullptr) {
+                               const ValueView& Q, hipStream_t s, const MfLabels* lab = nullptr, bool* labels_done = nullptr,
+                               int slot = 0, bool timed = true) {
     if (labels_done) *labels_done = false;
     rvseg_status st;
-    if ((st = dev_reserve(ctx, cs->tmp, (size_t)n_points * C * 4)) != RVSEG_OK) return st;
+    DevBuf& b_tmp = slot ? cs->tmp2 : cs->tmp;
+    DevBuf& b_qn = slot ? cs->qn2 : cs->qn;
+    DevBuf& b_va = slot ? cs->val_a2 : cs->val_a;
+    DevBuf& b_vb = slot ? cs->val_b2 : cs->val_b;
+    auto mark = [&](const char* name) { if (timed) timer_mark(ctx, name, s); };
+    if ((st = dev_reserve(ctx, b_tmp, (size_t)n_points * C * 4)) != RVSEG_OK) return st;
     long long mb = 0;
     for (int k = 0; k < n_kernels; k++) mb = std::max<long long>(mb, cs->lat[k].dev.m_bound);
-    if ((st = values_reserve(ctx, cs, mb, C)) != RVSEG_OK) return st;
-    float* tmp = cs->tmp.as<float>();
+    if ((st = values_reserve(ctx, cs, mb, C, slot)) != RVSEG_OK) return st;
+    float* tmp = b_tmp.as<float>();
     // Single Potts kernel with a fused instantiation: between iterations Q holds fl(Q * norm), the
     // input of the next splat (pairwise.cpp:66), so the splat is a plain gather; only the last
     // update stores the marginals themselves.
     bool fused = n_kernels == 1 && iterations > 0;
-    timer_mark(ctx, "softmax", s);
-    if (!launch_softmax_unary(unary, unary_is_energy, C, N, Q, n_points, fused ? cs->lat[0].dev.norm : nullptr, s)) {
+    // Where the fused loop keeps fl(Q * norm) between iterations: Q itself when that is one contiguous
+    // [point][C] matrix, else (a layer inside the reference's [layer][y][x][class] frames) a contiguous scratch
+    // matrix -- the splat then addresses a row as point * C without splitting the point index per frame, and
+    // its gathers stay inside one array.  The last update writes the marginals into Q in either case.
+    ValueView Qs = Q;
+    if (fused && !(Q.frame_stride == (size_t)N * (size_t)C && Q.layer_off == 0)) {
+        if ((st = dev_reserve(ctx, b_qn, (size_t)n_points * C * 4)) != RVSEG_OK) return st;
+        Qs = ValueView{b_qn.as<float>(), (size_t)N * (size_t)C, 0};
+    }
+    mark("softmax");
+    if (!launch_softmax_unary(unary, unary_is_energy, C, N, fused ? Qs : Q, n_points, fused ? cs->lat[0].dev.norm : nullptr, s)) {
         fused = false;
         launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
         launch_softmax(tmp, C, N, Q, n_points, s);
@@ -263,33 +287,60 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             // single Potts kernel: splat, blur, then one fused slice + update + softmax pass
             const LatticeBufs& b = cs->lat[0];
             const bool seq = C <= 2;
-            timer_mark(ctx, "splat", s);
-            launch_splat(b.dev, Q, C, fused ? 0 : 1, cs->val_a.as<float>(), s);
-            timer_mark(ctx, "blur", s);
-            float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
+            mark("splat");
+            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused);
+            mark("blur");
+            float* blurred = launch_blur(b.dev, C, seq, false, b_va.as<float>(), b_vb.as<float>(), s);
             if (fused) {
-                timer_mark(ctx, "mf_update", s);
+                mark("mf_update");
                 const bool last = it + 1 == iterations;
                 MfLabels none{nullptr, 0, 0, 0, 0};
-                launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, Q, !last, last && lab ? *lab : none, s);
+                launch_mf_update(b.dev, C, blurred, -ws[0], unary, unary_is_energy, last ? Q : Qs, !last, last && lab ? *lab : none, s);
                 if (last && lab && labels_done) *labels_done = true;
                 continue;
             }
-            timer_mark(ctx, "softmax", s);
+            mark("softmax");
             launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
-            timer_mark(ctx, "slice", s);
+            mark("slice");
             launch_slice(b.dev, C, seq, 2, blurred, -ws[0], tmp, n_points, s);
-            timer_mark(ctx, "softmax", s);
+            mark("softmax");
             launch_softmax(tmp, C, N, Q, n_points, s);
             continue;
         }
-        timer_mark(ctx, "softmax", s);
+        mark("softmax");
         launch_neg_unary(unary, unary_is_energy, C, N, tmp, n_points, s);
         for (int k = 0; k < n_kernels; k++) filter_into(ctx, cs->lat[k], cs, Q, C, ws[k], tmp, s);
-        timer_mark(ctx, "softmax", s);
+        mark("softmax");
         launch_softmax(tmp, C, N, Q, n_points, s);
     }
     RV_HIP(ctx, hipGetLastError());
+    return RVSEG_OK;
+}
+
+// The label layers of one lattice are independent mean fields (the reference runs one DenseCRF per layer,
+// segmenter.cpp:639-644).  Their splats wait for their longest chains rather than for bandwidth whenever a chunk
+// has few frames (a cloud, a 1280x960 chunk), so odd layers run on a second stream beside the even ones.
+static rvseg_status layer_stream_fork(rvseg_ctx* ctx, CrfState* cs, hipStream_t s, int n_layers, hipStream_t* s2) {
+    *s2 = s;
+    static const bool serial = std::getenv("RVSEG_NO_LAYER_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_LAYER_OVERLAP")) != 0;
+    if (n_layers < 2 || serial) return RVSEG_OK;
+    if (!cs->layer_stream) {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        RV_HIP(ctx, hipStreamCreateWithPriority(&cs->layer_stream, hipStreamNonBlocking, prio_hi));
+        RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_fork, hipEventDisableTiming));
+        RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_join, hipEventDisableTiming));
+    }
+    RV_HIP(ctx, hipEventRecord(cs->layer_fork, s));
+    RV_HIP(ctx, hipStreamWaitEvent(cs->layer_stream, cs->layer_fork, 0));
+    *s2 = cs->layer_stream;
+    return RVSEG_OK;
+}
+
+static rvseg_status layer_stream_join(rvseg_ctx* ctx, CrfState* cs, hipStream_t s, hipStream_t s2) {
+    if (s2 == s) return RVSEG_OK;
+    RV_HIP(ctx, hipEventRecord(cs->layer_join, s2));
+    RV_HIP(ctx, hipStreamWaitEvent(s, cs->layer_join, 0));
     return RVSEG_OK;
 }
 
@@ -361,6 +412,8 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
     int prefix = 0;
     const float w = p.dcrf_kernel_weight;
     bool all_labelled = true;   // the last fused update of every layer wrote its labels
+    hipStream_t s2;
+    if ((st = layer_stream_fork(ctx, cs, s, f.n_layers, &s2)) != RVSEG_OK) return st;
     for (int l = 0; l < f.n_layers; l++) {
         const int C = f.class_counts[l];
         ValueView U{const_cast<float*>(d_post), frame_stride, (size_t)N * prefix};
@@ -368,10 +421,13 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
         // unary energy = -(log-posterior) (segmenter.cpp:642), so -U is the posterior itself
         MfLabels lab{d_labels, p.label_mode, p.unknown_label[l], f.n_layers, l};
         bool done = false;
-        if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, s, d_labels ? &lab : nullptr, &done)) != RVSEG_OK) return st;
+        const int slot = l & 1;
+        if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, slot ? s2 : s, d_labels ? &lab : nullptr,
+                             &done, slot, slot == 0 || s2 == s)) != RVSEG_OK) { (void)layer_stream_join(ctx, cs, s, s2); return st; }
         all_labelled = all_labelled && done;
         prefix += C;
     }
+    if ((st = layer_stream_join(ctx, cs, s, s2)) != RVSEG_OK) return st;
     if (d_labels && !all_labelled) {
         timer_mark(ctx, "labels", s);
         launch_labels_frames(marg, n, N, f, p.label_mode, p.unknown_label, d_labels, s);
@@ -417,22 +473,30 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
     if ((st = lattice_build_retry(ctx, cs, cs->lat[0], 6, N, d_features, s)) != RVSEG_OK) return st;
     int cmax = 0;
     for (int l = 0; l < n_layers; l++) cmax = std::max(cmax, class_counts[l]);
-    if ((st = dev_reserve(ctx, cs->q, (size_t)N * cmax * 4)) != RVSEG_OK) return st;
+    // marginals of even / odd layers in two halves of cs->q (the odd layers run on the second stream)
+    if ((st = dev_reserve(ctx, cs->q, (size_t)N * cmax * 4 * 2)) != RVSEG_OK) return st;
+    hipStream_t s2;
+    if ((st = layer_stream_fork(ctx, cs, s, n_layers, &s2)) != RVSEG_OK) return st;
     size_t prefix = 0;
     for (int l = 0; l < n_layers; l++) {
         const int C = class_counts[l];
+        const int slot = l & 1;
+        hipStream_t sl = slot ? s2 : s;
+        float* q = cs->q.as<float>() + (size_t)slot * N * cmax;
         ValueView U{const_cast<float*>(d_unaries) + (size_t)N * prefix, (size_t)N * C, 0};
-        ValueView Q{cs->q.as<float>(), (size_t)N * C, 0};
+        ValueView Q{q, (size_t)N * C, 0};
         MfLabels lab{d_labels ? d_labels + (size_t)l * N : nullptr, label_mode, unknown[l], 1, 0};
         bool done = false;
         // crf.setUnaryEnergy(-unaries[l]) (segmenter.cpp:642): the accumulated posteriors ARE -energy
-        if ((st = mean_field(ctx, cs, 1, &potts_w, U, false, C, N, N, iterations, Q, s, d_labels ? &lab : nullptr, &done)) != RVSEG_OK) return st;
+        if ((st = mean_field(ctx, cs, 1, &potts_w, U, false, C, N, N, iterations, Q, sl, d_labels ? &lab : nullptr, &done, slot,
+                             slot == 0 || s2 == s)) != RVSEG_OK) { (void)layer_stream_join(ctx, cs, s, s2); return st; }
         if (d_labels && !done) {
-            timer_mark(ctx, "labels", s);
-            launch_labels(cs->q.as<float>(), (size_t)N, C, label_mode, unknown[l], d_labels + (size_t)l * N, s);
+            if (slot == 0 || s2 == s) timer_mark(ctx, "labels", sl);
+            launch_labels(q, (size_t)N, C, label_mode, unknown[l], d_labels + (size_t)l * N, sl);
         }
         prefix += C;
     }
+    if ((st = layer_stream_join(ctx, cs, s, s2)) != RVSEG_OK) return st;
     RV_HIP(ctx, hipGetLastError());
     return RVSEG_OK;
 }
