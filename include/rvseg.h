@@ -264,6 +264,22 @@ rvseg_status rvseg_process_map_device(rvseg_ctx *ctx, int32_t n_images, const in
 rvseg_status rvseg_label_values(rvseg_ctx *ctx, const float *values, int32_t N, int32_t C, int32_t label_mode,
                                 int32_t unknown_label, int8_t *labels_out);
 
+/* ---- multi-GPU: the local-map gather over RCCL.  The reference is a single process; the build
+ *      shards key frames over the GPUs of a node (one context per GPU, each in its own process or thread, no
+ *      data-path collective) and sends every rank's fixed-size block -- int8 labels n x L x H x W, or fp32
+ *      posteriors for the order-preserving fusion of src/segmenter.cpp:599-616 -- to the fusion rank: one
+ *      direct transfer per peer over xGMI.  librccl.so is opened on first use.
+ *        rvseg_comm_unique_id  rank 0 creates the 128-byte id; the host distributes it (any channel)
+ *        rvseg_comm_init       collective over all ranks (ncclCommInitRank)
+ *        rvseg_gather_frames   rank r's bytes_per_rank bytes land at d_recv + r * bytes_per_rank on `root`
+ *                              (d_recv is ignored elsewhere); enqueued on hip_stream, not waited for */
+#define RVSEG_COMM_ID_BYTES 128
+rvseg_status rvseg_comm_unique_id(uint8_t id_out[RVSEG_COMM_ID_BYTES]);
+rvseg_status rvseg_comm_init(rvseg_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RVSEG_COMM_ID_BYTES]);
+void rvseg_comm_destroy(rvseg_ctx *ctx);
+rvseg_status rvseg_gather_frames(rvseg_ctx *ctx, const void *d_local, size_t bytes_per_rank, void *d_recv,
+                                 int32_t root, void *hip_stream);
+
 /* ---- timing of the last segment_frames / crf_infer call, measured with HIP events on the
  *      stream the kernels ran on.  names_out receives a ';'-separated list of stage names,
  *      ms_out up to max_stages durations.  Returns the number of stages. */

@@ -27,6 +27,7 @@ SYMBOLS = [
     "rvseg_fuse_posteriors_device", "rvseg_cloud_features_device", "rvseg_crf_infer_device",
     "rvseg_label_values_device", "rvseg_process_map_device",
     "rvseg_crf_features_gaussian", "rvseg_crf_features_bilateral",
+    "rvseg_comm_unique_id", "rvseg_comm_init", "rvseg_comm_destroy", "rvseg_gather_frames",
 ]
 
 
@@ -105,6 +106,11 @@ def lib():
     L.rvseg_crf_infer_device.argtypes = [vp, i32, i32, i32, vp, i32, vp, f32, i32, vp, vp, i32, i32, vp]
     L.rvseg_label_values_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.rvseg_process_map_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.rvseg_comm_unique_id.argtypes = [vp]
+    L.rvseg_comm_init.argtypes = [vp, i32, i32, vp]
+    L.rvseg_comm_destroy.argtypes = [vp]
+    L.rvseg_comm_destroy.restype = None
+    L.rvseg_gather_frames.argtypes = [vp, vp, C.c_size_t, vp, i32, vp]
     L.rvseg_crf_features_gaussian.argtypes = [i32, i32, f32, f32, vp]
     L.rvseg_crf_features_bilateral.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, vp]
     for name in SYMBOLS:

@@ -250,11 +250,13 @@ rvseg_status rvseg_create(const rvseg_params* params, rvseg_ctx** out) {
 }
 
 void rvseg_pipeline_destroy(rvseg_ctx* ctx);  // rvseg_pipeline.hip
+void rvseg_comm_destroy(rvseg_ctx* ctx);      // rvseg_comm.cpp
 
 void rvseg_destroy(rvseg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->params.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rvseg_comm_destroy(ctx);
     rvseg_pipeline_destroy(ctx);
     dev_free(ctx->forest.nodes);
     dev_free(ctx->forest.roots);

@@ -71,6 +71,8 @@ struct rvseg_ctx {
     rvseg::StageTimer timer;
     struct Impl;
     Impl* impl = nullptr;  // frame / crf pipeline state (rvseg_pipeline.hip)
+    void* comm = nullptr;  // RCCL communicator of the local-map gather (rvseg_comm.cpp), or null
+    int comm_rank = 0, comm_world = 0;
 };
 
 namespace rvseg {

@@ -189,6 +189,22 @@ class Context:
             self.h, N, Cn, d, C.c_void_p(d_unary), 1 if unary_is_energy else 0, C.c_void_p(d_features), C.c_float(potts_w),
             iterations, C.c_void_p(d_Q or None), C.c_void_p(d_map or None), label_mode, unknown_label, C.c_void_p(stream or None)))
 
+    # ---- multi-GPU local-map gather over RCCL ------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        st = capi.lib().rvseg_comm_unique_id(buf)
+        if st != capi.OK:
+            raise capi.RvsegError(st, "rvseg_comm_unique_id failed (librccl.so missing?)")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        capi.check(self.h, self.L.rvseg_comm_init(self.h, rank, world, bytes(unique_id)))
+
+    def gather_frames(self, d_local, bytes_per_rank, d_recv=0, root=0, stream=0):
+        capi.check(self.h, self.L.rvseg_gather_frames(self.h, C.c_void_p(d_local), bytes_per_rank, C.c_void_p(d_recv or None), root,
+                                                      C.c_void_p(stream or None)))
+
     def label_values(self, values, label_mode, unknown_label=0):
         V = np.ascontiguousarray(values, np.float32)
         N, Cn = V.shape

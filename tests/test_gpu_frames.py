@@ -154,3 +154,46 @@ def test_rf_frames_strides_and_feature_toggles(gpu_ctx_factory, oracle, stride, 
     out = ctx.segment_frames(rgb[None], depth[None], calib)
     want, _ = oracle.rf_frame(oracle.default_params(**kw), forest, 1, rgb, depth, calib)
     assert np.array_equal(out["posteriors"][0], want)
+
+
+def test_lazy_walk_touches_every_feature(gpu_ctx_factory, oracle):
+    """The production kernel (rf_frames_lazy_kernel) computes a patch value only when a node tests it, so
+    a small forest exercises a small part of the 363 cells.  64 trees x 512 leaves = 32 704 inner nodes:
+    every one of the 366 features is split on (asserted below), ~90 times each with thresholds spread
+    over the value range, and the posteriors of every sample point must still equal the oracle's."""
+    import struct
+    W, H = 160, 120
+    blob = synthetic.make_forest_bytes(seed=77, n_trees=64, leaves_per_tree=512, max_depth=14)
+    # features that inner nodes split on (stream layout: int32 T, then per tree vec<int32> features, ...)
+    pos, used = 4, set()
+    for _ in range(64):
+        n = struct.unpack_from("<i", blob, pos)[0]
+        feat = np.frombuffer(blob, np.int32, n, pos + 4)
+        left = np.frombuffer(blob, np.int32, n, pos + 4 + 4 * n + 4 + 4 * n + 4)
+        used |= set(feat[left != 0].tolist())
+        pos += 3 * (4 + 4 * n)
+        for _vec in range(2):   # histograms, multi_histograms: skip by walking the length prefixes
+            cnt = struct.unpack_from("<i", blob, pos)[0]
+            pos += 4
+            for _i in range(cnt):
+                m = struct.unpack_from("<i", blob, pos)[0]
+                pos += 4
+                if _vec == 0:
+                    pos += 4 * m
+                else:
+                    for _l in range(m):
+                        c = struct.unpack_from("<i", blob, pos)[0]
+                        pos += 4 + 4 * c
+    assert used == set(range(366))
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(2, W, H, holes=True, start=3)
+    depth[1, :, : W // 2] = 520       # near plane: the widest ROIs (half = 74), reflected border in play
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(width=W, height=H, max_batch=2)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib, want_labels=False)
+    p = oracle.default_params(width=W, height=H)
+    for i in range(2):
+        want, P = oracle.rf_frame(p, forest, 1, rgb[i], depth[i], calib)
+        assert P > 1000
+        assert np.array_equal(out["posteriors"][i], want), i
