@@ -4,6 +4,9 @@
 // Reference: include/feature_extractor.h:125-291.  The arithmetic of cvtColor / PCL normals lives
 // in libraries the reference does not vendor; the definitions implemented here are the ones
 // written down in DESIGN.md and restated independently by the CPU oracle.
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_math.h"
 #include "rvseg_internal.h"
 #include "rvseg_kernels.h"
@@ -230,6 +233,10 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
 // with n = normalise(sum_window(dy) x sum_window(dx)), gradients summed as 2^-32 fixed-point int64
 // (exact, order independent).  One thread per sample point.
 // ---------------------------------------------------------------------------------------------
+// v * 2^32 rounded to the nearest integer (ties to even), clamped to +-9e18 -- the oracle computes the same with
+// llrint.  (An integer-only form built from the float's mantissa -- profiles/analysis/fix32_check.cpp proves it
+// equal on 4e8 random and all boundary encodings -- measured 100 us SLOWER per 64-frame launch than this f64
+// sequence: variable 64-bit shifts are not cheaper than the double-rate multiply and conversion.)
 __device__ __forceinline__ long long to_fix32(float v) {
     double s = (double)v * 4294967296.0;
     s = s > 9.0e18 ? 9.0e18 : s;
@@ -312,19 +319,23 @@ constexpr int NF_THREADS = NF_TY * NF_TX * NF_PARTS;
 
 __global__ void __launch_bounds__(NF_THREADS)
 normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const uint8_t* __restrict__ rect_all,
-                            float* __restrict__ nfeat_all, int tiles_x, int tiles_y) {
+                            float* __restrict__ nfeat_all, int tiles_x, int tiles_y, int n_jobs) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sat[];   // [NF_PLANES][th + 1][tw + 1]
     const int s = g.stride;
     const int tw = NF_TX * s + 2 * NF_APRON, th = NF_TY * s + 2 * NF_APRON;
     const int pw = tw + 1, ph = th + 1;           // padded plane: row 0 and column 0 stay zero
     const int plane = pw * ph;
     const int W = g.W, H = g.H;
-    const int frame = blockIdx.x / (tiles_x * tiles_y);
-    const int tile = blockIdx.x - frame * tiles_x * tiles_y;
+    const int tid = threadIdx.x;
+    // a block walks several tiles (grid = a few blocks per CU).  Measured per 64-frame launch with phases
+    // switched off: cloud loads 215 us, fixed-point conversion 175, the two prefix passes 330, window
+    // evaluation 105, the rest 160; 2 / 4 / 8 / 75 blocks per CU: 774 / 766 / 747 / 759 us -- turnover is not it
+  for (int job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+    const int frame = job / (tiles_x * tiles_y);
+    const int tile = job - frame * tiles_x * tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int px0 = tx * NF_TX * s - NF_APRON, py0 = ty * NF_TY * s - NF_APRON;   // pixel of tile cell (0,0)
     const float4* cloud = cloud_all + (size_t)frame * W * H;
-    const int tid = threadIdx.x;
     // ---- gradients (PCL: central differences of the organised cloud), one padded cell per thread step
     for (int idx = tid; idx < plane; idx += NF_THREADS) {
         const int cy = idx / pw, cx = idx - cy * pw;
@@ -348,7 +359,9 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
         sat[6 * plane + idx] = (unsigned long long)cnt_x | ((unsigned long long)cnt_y << 32);   // two int32 counters, no carry between them (<= 1232 each)
     }
     __syncthreads();
-    // ---- prefix along x: one thread per (plane, row) walks its row (unsigned: wrap-around is harmless)
+    // ---- prefix along x: one thread per (plane, row) walks its row (unsigned: wrap-around is harmless).
+    //      (Reading a batch of cells into registers before writing any back, to keep several LDS reads in
+    //      flight, measured 150 us slower per 64-frame launch than this plain loop.)
     for (int t = tid; t < NF_PLANES * th; t += NF_THREADS) {
         const int k = t / th, cy = t - k * th + 1;
         unsigned long long* row = sat + (size_t)k * plane + (size_t)cy * pw;
@@ -408,22 +421,25 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
     const long long gy1 = (long long)__shfl(a, base + 2, 64), gy2 = (long long)__shfl(b, base + 2, 64);
     const unsigned long long cnt = __shfl(a, base + 3, 64);
     const int cnt_x = (int)(unsigned)cnt, cnt_y = (int)(unsigned)(cnt >> 32);
-    if (!inside || part != 0) return;
-    float out = -2.0f;
-    if (rect > 0 && cnt_x > 0 && cnt_y > 0) {
-        const double k = 1.0 / 4294967296.0;
-        const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
-        const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
-        const double n0 = GY1 * GX2 - GY2 * GX1;
-        const double n1 = GY2 * GX0 - GY0 * GX2;
-        const double n2 = GY0 * GX1 - GY1 * GX0;
-        const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
-        if (len2 != 0.0) {
-            const float nz = (float)(n2 / sqrt(len2));
-            if (nz == nz) out = acos_f32_dev(fabsf(nz));
+    if (inside && part == 0) {
+        float out = -2.0f;
+        if (rect > 0 && cnt_x > 0 && cnt_y > 0) {
+            const double k = 1.0 / 4294967296.0;
+            const double GX0 = (double)gx0 * k, GX1 = (double)gx1 * k, GX2 = (double)gx2 * k;
+            const double GY0 = (double)gy0 * k, GY1 = (double)gy1 * k, GY2 = (double)gy2 * k;
+            const double n0 = GY1 * GX2 - GY2 * GX1;
+            const double n1 = GY2 * GX0 - GY0 * GX2;
+            const double n2 = GY0 * GX1 - GY1 * GX0;
+            const double len2 = (n0 * n0 + n1 * n1) + n2 * n2;
+            if (len2 != 0.0) {
+                const float nz = (float)(n2 / sqrt(len2));
+                if (nz == nz) out = acos_f32_dev(fabsf(nz));
+            }
         }
+        nfeat_all[(size_t)frame * g.lw * g.lh + (size_t)ly_s * g.lw + lx_s] = out;
     }
-    nfeat_all[(size_t)frame * g.lw * g.lh + (size_t)ly_s * g.lw + lx_s] = out;
+    __syncthreads();   // the table is rewritten by the next tile
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,8 +471,11 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
-        normal_feature_tiled_kernel<<<dim3((unsigned)(tiles_x * tiles_y * n)), dim3(NF_THREADS), lds, s>>>(
-            g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y);
+        const int n_jobs = tiles_x * tiles_y * n;
+        static const int per_cu = std::getenv("RVSEG_NF_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_NF_BLOCKS_PER_CU")) : 8;
+        const int grid = std::min(n_jobs, 256 * std::max(1, per_cu));   // two resident per CU (LDS); the rest queue once
+        normal_feature_tiled_kernel<<<dim3((unsigned)grid), dim3(NF_THREADS), lds, s>>>(
+            g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y, n_jobs);
         return;
     }
     const int total = g.lw * g.lh * n;
