@@ -82,7 +82,8 @@ def pmc_traffic(stage):
         return None
     with open(f) as fh:
         d = json.load(fh)
-    r = d.get(STAGE_KERNEL[stage])
+    want = STAGE_KERNEL[stage].rstrip(">")   # template arguments added later (block shape ...) follow the ones named here
+    r = next((v for k, v in sorted(d.items()) if k == STAGE_KERNEL[stage] or k.startswith(want + ",")), None)
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
         return None
     factor = 2.0
