@@ -130,6 +130,30 @@ rvseg_status rvseg_forest_write_mem(const rvseg_ctx *ctx, void *out, size_t out_
 /* The same writer without a context: parse `buf`, serialise it again (host only; used by the CPU tests
  * to pin the writer against the reference-written golden files). */
 rvseg_status rvseg_forest_rewrite(const void *buf, size_t size, void *out, size_t out_cap, size_t *size_out);
+/* ---- forest training on the GPU: replaces RandomForestLearner::learn + DecisionTreeLearner::learn +
+ *      updateMultiHistograms + forest->write (libforest learning.cpp:410-1073, src/train.cpp:225-249) for the
+ *      model family this path evaluates.  Parameters = the learner settings of src/train.cpp / config.json. */
+typedef struct rvseg_train_params {
+    int32_t num_trees;                /* config.json:37 (4)                                                   */
+    int32_t max_depth;                /* config.json:38 (30): a node deeper than this is not split (learning.cpp:525) */
+    int32_t min_split_examples;       /* config.json:39 (50)                                                  */
+    int32_t min_child_split_examples; /* learning.h:116 (1)                                                   */
+    int32_t num_features;             /* features tried per node; 0 = ceil(sqrt(D)) (autoconf, learning.cpp:367) */
+    int32_t use_bootstrap;            /* 1 (train.cpp:226): N draws with replacement per tree                 */
+    float smoothing;                  /* learning.h:117 (1): log((h + s) / (total + C s))                     */
+    uint64_t seed;                    /* the reference seeds from std::random_device (learning.cpp:18) and is
+                                         not reproducible; here equal seeds give equal bytes                  */
+} rvseg_train_params;
+void rvseg_train_params_default(rvseg_train_params *tp);
+/* X: P x D host floats (one DataPoint per row), labels: P x n_layers class indices (DataStorage's multi labels),
+ * class_counts per layer (at most 16 each).  Writes a forest.dat image (multi_histograms = the "shared" forest of
+ * train.cpp:231; with one layer also `histograms`), loadable with rvseg_forest_load_mem and by the reference.
+ * forest_out may be NULL to query *size_out.  Search = the reference's criterion (minimum of E(left) + E(right),
+ * thresholds at midpoints of adjacent distinct values: exact for byte-valued features, 256 uniform bins for
+ * the others); leaf histograms exactly as updateMultiHistograms computes them (learning.cpp:960-1012). */
+rvseg_status rvseg_forest_train(rvseg_ctx *ctx, const float *X, int32_t P, int32_t D, const int32_t *labels,
+                                int32_t n_layers, const int32_t *class_counts, const rvseg_train_params *tp,
+                                void *forest_out, size_t out_cap, size_t *size_out);
 /* n_layers / class_counts describe the active mode (multi_layer or single). */
 rvseg_status rvseg_forest_info(const rvseg_ctx *ctx, int32_t *n_trees, int32_t *n_nodes_total,
                                int32_t *max_depth, int32_t *n_layers,

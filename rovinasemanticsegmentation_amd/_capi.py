@@ -27,6 +27,7 @@ SYMBOLS = [
     "rvseg_fuse_posteriors_device", "rvseg_cloud_features_device", "rvseg_crf_infer_device",
     "rvseg_label_values_device", "rvseg_process_map_device",
     "rvseg_crf_features_gaussian", "rvseg_crf_features_bilateral",
+    "rvseg_train_params_default", "rvseg_forest_train",
     "rvseg_comm_unique_id", "rvseg_comm_init", "rvseg_comm_destroy", "rvseg_gather_frames",
 ]
 
@@ -45,6 +46,14 @@ class RvsegParams(C.Structure):
         ("multi_layer", C.c_int32), ("label_mode", C.c_int32),
         ("unknown_label", C.c_int32 * RVSEG_MAX_LAYERS),
         ("max_batch", C.c_int32), ("device", C.c_int32), ("lattice_capacity_log2", C.c_int32),
+    ]
+
+
+class RvsegTrainParams(C.Structure):
+    _fields_ = [
+        ("num_trees", C.c_int32), ("max_depth", C.c_int32), ("min_split_examples", C.c_int32),
+        ("min_child_split_examples", C.c_int32), ("num_features", C.c_int32), ("use_bootstrap", C.c_int32),
+        ("smoothing", C.c_float), ("seed", C.c_uint64),
     ]
 
 
@@ -106,6 +115,9 @@ def lib():
     L.rvseg_crf_infer_device.argtypes = [vp, i32, i32, i32, vp, i32, vp, f32, i32, vp, vp, i32, i32, vp]
     L.rvseg_label_values_device.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     L.rvseg_process_map_device.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.rvseg_train_params_default.argtypes = [C.POINTER(RvsegTrainParams)]
+    L.rvseg_train_params_default.restype = None
+    L.rvseg_forest_train.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.POINTER(RvsegTrainParams), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rvseg_comm_unique_id.argtypes = [vp]
     L.rvseg_comm_init.argtypes = [vp, i32, i32, vp]
     L.rvseg_comm_destroy.argtypes = [vp]

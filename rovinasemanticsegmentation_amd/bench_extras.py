@@ -150,6 +150,33 @@ def _config5(ctx_factory, dev, blob, rgb, depth, calib):
         ctx.close()
 
 
+def _train(ctx_factory, dev, blob, rgb, depth, calib):
+    """Forest training on the GPU (rvseg_forest_train): the reference's learner settings (4 trees, depth 30,
+    min_split 50, bootstrap, sqrt(D) features per node) on features the library extracts from 8 bench frames."""
+    ctx = ctx_factory()
+    try:
+        feats, labs = [], []
+        for i in range(8):
+            f, xs, ys = ctx.extract_features(rgb[i], depth[i], calib)
+            feats.append(f)
+            # two label layers from image position + depth, like label images sampled at (x_v, y_v)
+            l0 = ((xs // 80) + 2 * (ys // 120)) % 8
+            l1 = ((xs // 64) + (f[:, 363] > 2.5).astype(np.int64) * 3 + (ys // 160)) % 9
+            labs.append(np.stack([l0, l1], 1).astype(np.int32))
+        X, Y = np.concatenate(feats), np.concatenate(labs)
+        t0 = time.perf_counter()
+        model = ctx.forest_train(X, Y, [8, 9], num_trees=4, max_depth=30, min_split_examples=50, seed=1)
+        dt = time.perf_counter() - t0
+        ctx.forest_load(model)
+        info = ctx.forest_info()
+        return {"seconds": round(dt, 3), "examples": int(X.shape[0]), "features": int(X.shape[1]), "layers": [8, 9],
+                "trees": info["n_trees"], "nodes": info["n_nodes"], "max_depth": info["max_depth"], "model_bytes": len(model),
+                "examples_per_s_per_tree": round(X.shape[0] * 4 / dt),
+                "note": "level-wise histogram search on the GPU, learner settings of src/train.cpp:225-239 / config.json:37-39"}
+    finally:
+        ctx.close()
+
+
 def run(ctx, dev, blob, rgb_h, depth_h, calib, want=None):
     import rovinasemanticsegmentation_amd as rv
 
@@ -164,11 +191,12 @@ def run(ctx, dev, blob, rgb_h, depth_h, calib, want=None):
             out["host_path_mpix_s"] = {"labels_only": r["labels_only"]["mpix_s"], "labels_and_marginals": r["labels_and_marginals"]["mpix_s"]}
         except Exception as e:  # an extra must never take the headline down with it
             out["host_path"] = {"error": repr(e)}
-    for name, fn in (("localmap", globals().get("_local_map")), ("config5", globals().get("_config5"))):
+    keys = {"localmap": "local_map", "config5": "config5_1gpu", "train": "forest_train"}
+    for name, fn in (("localmap", globals().get("_local_map")), ("config5", globals().get("_config5")), ("train", globals().get("_train"))):
         if fn is None or not (want is None or name in want):
             continue
         try:
-            out[{"localmap": "local_map", "config5": "config5_1gpu"}[name]] = fn(factory, dev, blob, rgb_h, depth_h, calib)
+            out[keys[name]] = fn(factory, dev, blob, rgb_h, depth_h, calib)
         except Exception as e:
-            out[{"localmap": "local_map", "config5": "config5_1gpu"}[name]] = {"error": repr(e)}
+            out[keys[name]] = {"error": repr(e)}
     return out

@@ -72,6 +72,30 @@ class Context:
         capi.check(self.h, self.L.rvseg_forest_write_mem(self.h, buf, size.value, C.byref(size)))
         return buf.raw[:size.value]
 
+    def forest_train(self, X, labels, class_counts, **train_params):
+        """rvseg_forest_train: X (P, D) float32, labels (P, L) int32 class indices.  Returns the forest.dat bytes.
+        train_params: fields of rvseg_train_params (num_trees, max_depth, min_split_examples, ...)."""
+        X = np.ascontiguousarray(X, np.float32)
+        labels = np.ascontiguousarray(np.asarray(labels, np.int32).reshape(X.shape[0], -1))
+        P, D = X.shape
+        L = labels.shape[1]
+        assert len(class_counts) == L
+        tp = capi.RvsegTrainParams()
+        self.L.rvseg_train_params_default(C.byref(tp))
+        for k, v in train_params.items():
+            setattr(tp, k, v)
+        cc = (C.c_int32 * L)(*class_counts)
+        size = C.c_size_t()
+        cap = 64 << 20
+        while True:
+            buf = C.create_string_buffer(cap)
+            st = self.L.rvseg_forest_train(self.h, _ptr(X), P, D, _ptr(labels), L, cc, C.byref(tp), buf, cap, C.byref(size))
+            if st == capi.ERR_INVALID_ARG and size.value > cap:
+                cap = size.value
+                continue
+            capi.check(self.h, st)
+            return buf.raw[:size.value]
+
     def poll_status(self, wait=True):
         """Status of the asynchronous part of the last segment_frames_device call: capi.OK,
         capi.NOT_READY (only with wait=False) or raises RvsegError(ERR_CAPACITY)."""
