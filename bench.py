@@ -128,7 +128,7 @@ def launch_ranks(args):
     torch.cuda.device_count() (does not create a context on this image) and the children are started
     with subprocess (never exec after GPU init)."""
     n = args.gpus
-    if not args.rehearsal:
+    if not args.rehearsal and os.environ.get("RVSEG_BENCH_SAME_DEVICE", "0") != "1":   # (one-GPU rehearsal of the rank code path)
         import torch
         have = torch.cuda.device_count()
         if have < n:
@@ -293,7 +293,7 @@ def main():
                      unknown_label=[8], max_batch=n, device=dev.index or 0,
                      # the Segmenter kernel (xyz*0.5, rgb*4) yields ~300 lattice vertices per frame;
                      # 2^12 slots per frame keep the per-vertex launches small (overflow is detected)
-                     lattice_capacity_log2=12)
+                     lattice_capacity_log2=int(os.environ.get("RVSEG_BENCH_CAPACITY_LOG2", "12")))
     ctx.forest_load(blob)
     stream = torch.cuda.current_stream(dev)
 

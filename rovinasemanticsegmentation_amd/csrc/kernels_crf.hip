@@ -420,7 +420,7 @@ void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s);
 //   pass 2 (scatter) same walk, entries land at base + rank
 // ---------------------------------------------------------------------------------------------
 constexpr int CS_PIX = 256;
-constexpr int CS_MCAP = 2048;
+constexpr int CS_MCAP = 4096;   // 4 waves x 4096 counters = 64 KB of LDS at the largest fast-path capacity (2^13 slots per frame)
 
 // bh holds, per frame, a dense [wave-block][vertex] matrix with row stride M_f; the frame's matrix
 // starts at wbpf * fstart[frame] (so the whole array needs wbpf * M_total words).

@@ -472,8 +472,11 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
         }
         const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
         const int n_jobs = tiles_x * tiles_y * n;
-        static const int per_cu = std::getenv("RVSEG_NF_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_NF_BLOCKS_PER_CU")) : 8;
-        const int grid = std::min(n_jobs, 256 * std::max(1, per_cu));   // two resident per CU (LDS); the rest queue once
+        // one tile per block by default: a grid of long-lived blocks (RVSEG_NF_BLOCKS_PER_CU = 2..8) runs this kernel
+        // alone as fast (747-774 vs 759 us) but keeps the lattice build on the side stream off the CUs for its whole
+        // duration (build 3.5 -> 5.3 ms, step +0.3 ms)
+        static const int per_cu = std::getenv("RVSEG_NF_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_NF_BLOCKS_PER_CU")) : 0;
+        const int grid = per_cu > 0 ? std::min(n_jobs, 256 * per_cu) : n_jobs;
         normal_feature_tiled_kernel<<<dim3((unsigned)grid), dim3(NF_THREADS), lds, s>>>(
             g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y, n_jobs);
         return;

@@ -361,7 +361,13 @@ rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait) {
     if (cs->h_counters[1]) {
         const FrameGeom& g = im->geom;
         const bool was_worst = capacity_is_worst_case(ctx, g.W * g.H, 6);
-        im->cap_boost += 3;
+        // x8 slots per step, but stop at 2^13 on the way up: the largest capacity the counting-sort CSR path serves
+        // (real scenes with a deep range have ~2 000 vertices per frame; beyond it the radix-sort path takes over)
+        {
+            int base = ctx->params.lattice_capacity_log2 > 0 ? ctx->params.lattice_capacity_log2 : 12;
+            const int cur = base + im->cap_boost;
+            im->cap_boost += cur < 13 ? std::min(3, 13 - cur) : 3;
+        }
         ctx->err = was_worst ? "lattice hash table overflowed at its worst-case capacity (internal error)"
                              : "lattice hash table overflowed: the outputs of that call are invalid; the context has raised its "
                                "capacity (x8 slots per frame), repeat the call (or set params.lattice_capacity_log2 = -1)";
