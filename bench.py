@@ -385,7 +385,7 @@ def main():
             "config": {"workload": "batch of %d synthetic 640x480 RGB-D key frames per GPU, 4-tree forest "
                                    "(2^14 leaves/tree, D=366, C=9), RF + 5-iter DenseCRF (d=6, Potts w=10), "
                                    "marginals + labels written to HBM" % n,
-                       "frames_per_step_per_gpu": n, "label_gather": "rccl gather to rank 0" if world > 1 else "none"},
+                       "frames_per_step_per_gpu": n, "label_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none"},
             "roofline": roof,
             "verified": (verified["ok"] if verified else None), "verification": verified,
             "async_status": "ok" if async_status == rv.capi.OK else str(async_status),

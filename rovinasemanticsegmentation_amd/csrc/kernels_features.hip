@@ -106,6 +106,10 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
 // ---------------------------------------------------------------------------------------------
 constexpr int DM_TW = 64, DM_TH = 16, DM_APRON = 20;
 constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 104
+// row pitch of the LDS table.  Lane l touches row l at column t - 2l, i.e. word (pitch - 2) * l + t: with pitch 104
+// lanes l and l + 16 of a 32-lane group met in one bank (PMC: 62 % of the LDS-active cycles were conflict cycles);
+// an odd multiplier spreads a group over all 32 banks
+constexpr int DM_PITCH = DM_CW + 1;
 constexpr int DM_CH = DM_TH + 2 * DM_APRON;  // 56
 
 // value of the lane below in the wave (lane l takes lane l-1's); lane 0 takes `edge`
@@ -116,7 +120,7 @@ __device__ __forceinline__ float wave_shr1(float v, float edge) {
 
 __global__ void __launch_bounds__(64)
 window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* __restrict__ rect_all) {
-    __shared__ float dist[DM_CH * DM_CW];
+    __shared__ float dist[DM_CH * DM_PITCH];
     __shared__ int any_zero;
     const int W = g.W, H = g.H;
     const int tiles_x = (W + DM_TW - 1) / DM_TW;
@@ -138,7 +142,7 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
         const int r = y0 + lr, c = x0 + lc;
         float v = BIG;
         if (r >= 0 && r < H && c >= 0 && c < W && change[(size_t)r * W + c]) { v = 0.0f; my_zero = 1; }
-        dist[idx] = v;
+        dist[lr * DM_PITCH + lc] = v;
     }
     if (my_zero) any_zero = 1;
     __syncthreads();
@@ -161,7 +165,7 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
             const int lo = 1 - x0 > 0 ? 1 - x0 : 0, hi0 = W - x0 < DM_CW ? W - x0 : DM_CW;   // updated columns [lo, hi)
             const int hi = hi0 < lo ? lo : hi0;
             const int edge = W - 1 - x0;                  // tile column of the last image column
-            float* rowp = dist + (row_ok ? lr : 0) * DM_CW;
+            float* rowp = dist + (row_ok ? lr : 0) * DM_PITCH;
             float o1 = BIG, o2 = BIG, o3 = BIG;          // this lane's results at steps t-1, t-2, t-3
             int lc = -2 * lane;
             float center_next = (row_ok && lc >= 0 && lc < DM_CW) ? rowp[lc] : BIG;
@@ -193,7 +197,7 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
             const int lo = DM_CW - lhi, hi1 = DM_CW - llo;   // the same range in cp
             const int hi = hi1 < lo ? lo : hi1;
             const int edge = DM_CW - 1 + x0;                 // cp of image column 0: cells with cp >= edge have no lowerLeft
-            float* rowp = dist + (row_ok ? lr : 0) * DM_CW;
+            float* rowp = dist + (row_ok ? lr : 0) * DM_PITCH;
             float o1 = BIG, o2 = BIG, o3 = BIG;
             int cp = -2 * lane;                          // mirrored column index
             float center_next = (row_ok && cp >= 0 && cp < DM_CW) ? rowp[DM_CW - 1 - cp] : BIG;
@@ -221,7 +225,7 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
         const int lr = idx / DM_TW + DM_APRON, lc = idx % DM_TW + DM_APRON;
         const int r = y0 + lr, c = x0 + lc;
         if (r < H && c < W) {
-            const float dv = dist[lr * DM_CW + lc];
+            const float dv = dist[lr * DM_PITCH + lc];
             const float smoothing = dv < 10.0f ? dv : 10.0f;
             rect[(size_t)r * W + c] = smoothing > 2.0f ? (uint8_t)(int)smoothing : (uint8_t)0;
         }
@@ -239,6 +243,13 @@ window_map_kernel(FrameGeom g, const uint8_t* __restrict__ change_all, uint8_t* 
 // sequence: variable 64-bit shifts are not cheaper than the double-rate multiply and conversion.)
 __device__ __forceinline__ long long to_fix32(float v) {
     double s = (double)v * 4294967296.0;
+    // |s| < 2^51 (|v| < 2^19, any gradient of metric coordinates): s + 1.5 * 2^52 is rounded by the addition itself
+    // (nearest, ties to even) and its low bits ARE the integer -- one f64 add and one 64-bit subtract instead of the
+    // library's f64 -> i64 routine (gfx950 has no such conversion instruction)
+    if (fabs(s) < 2251799813685248.0) {
+        const double magic = 6755399441055744.0;   // 1.5 * 2^52
+        return __double_as_longlong(s + magic) - __double_as_longlong(magic);
+    }
     s = s > 9.0e18 ? 9.0e18 : s;
     s = s < -9.0e18 ? -9.0e18 : s;
     return __double2ll_rn(s);

@@ -182,10 +182,9 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
                 const uint2 yr = *reinterpret_cast<const uint2*>(&rt[half].y[dy]);
                 const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
                 const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
-                const int sx1 = sx0 + 1 < size ? sx0 + 1 : sx0;
-                int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = sy0 + 1;
-                sy0 = sy0 < 0 ? 0 : (sy0 >= size ? size - 1 : sy0);
-                sy1 = sy1 < 0 ? 0 : (sy1 >= size ? size - 1 : sy1);
+                const int sx1 = (int)(short)(xr.y >> 16);
+                const int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = (int)(short)(yr.y >> 16);
+                (void)size;
                 const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
                 const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
                 const uint32_t* lab = lab_all + (size_t)s[7] * W * H;
@@ -347,10 +346,8 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
         const uint2 yr = *reinterpret_cast<const uint2*>(&myrt->y[dy]);
         const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
         const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
-        const int sx1 = sx0 + 1 < size ? sx0 + 1 : sx0;
-        int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = sy0 + 1;
-        sy0 = sy0 < 0 ? 0 : (sy0 >= size ? size - 1 : sy0);
-        sy1 = sy1 < 0 ? 0 : (sy1 >= size ? size - 1 : sy1);
+        const int sx1 = (int)(short)(xr.y >> 16);
+        const int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = (int)(short)(yr.y >> 16);
         const int rx0 = reflect_idx(x0 + sx0, W), rx1 = reflect_idx(x0 + sx1, W);
         const int ry0 = reflect_idx(y0 + sy0, H), ry1 = reflect_idx(y0 + sy1, H);
         int xb = rx0 < rx1 ? rx0 : rx1;
@@ -366,6 +363,33 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
         v = v < 0 ? 0 : (v > 255 ? 255 : v);
         return (float)v;
     };
+    // The same value when the ROI of every point of the wave lies strictly inside the image (no mirrored border: all
+    // but a ~25-pixel frame of the sample points at the bench's depths): the taps are at (y0 + sy, x0 + sx) directly and
+    // the second column is the first one's right neighbour or itself.  PMC: this kernel is VALU bound (64 % of the
+    // issue cycles, 83 vector instructions per tree level); the four reflections and the pair selection were ~30 of them.
+    const int lab_base = y0 * W + x0;
+    auto patch_value_inside = [&](int packed) -> float {
+        const int c = packed >> 16, dy = (packed >> 8) & 255, dx = packed & 255;
+        const uint2 xr = *reinterpret_cast<const uint2*>(&myrt->x[dx]);
+        const uint2 yr = *reinterpret_cast<const uint2*>(&myrt->y[dy]);
+        const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
+        const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
+        const bool two = (int)(short)(xr.y >> 16) != sx0;
+        const int sy0 = (int)(short)(yr.x & 0xffffu), sy1 = (int)(short)(yr.y >> 16);
+        const u32x2_u q0 = *reinterpret_cast<const u32x2_u*>(lab + (lab_base + sy0 * W + sx0));
+        const u32x2_u q1 = *reinterpret_cast<const u32x2_u*>(lab + (lab_base + sy1 * W + sx0));
+        const int sh = 8 * c;
+        const int a00 = (int)((q0.x >> sh) & 255u), a01 = (int)(((two ? q0.y : q0.x) >> sh) & 255u);
+        const int a10 = (int)((q1.x >> sh) & 255u), a11 = (int)(((two ? q1.y : q1.x) >> sh) & 255u);
+        const int r0 = a00 * ia0 + a01 * ia1;
+        const int r1 = a10 * ia0 + a11 * ia1;
+        int v = (((ib0 * (r0 >> 4)) >> 16) + ((ib1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        return (float)v;
+    };
+    // strictly inside: the 8-byte tap load at column x0 + sx0 <= x0 + size - 1 must not be the image's last column
+    const bool roi_inside = x0 >= 0 && y0 >= 0 && x0 + size < W && y0 + size <= H;
+    const bool wave_inside = __ballot(valid && !roi_inside) == 0ull;
 
     // lanes = (point, tree); findLeafNode (classifier.cpp:97-117)
     int leaf_rows[16];
@@ -380,7 +404,7 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
                 const int4 c0 = np[nd.z], c1 = np[nd.z + 1];
                 const int f = nd.x;
                 float v;
-                if (f < g.n_patch) v = patch_value(nd.w);
+                if (f < g.n_patch) v = (g.debug_skip & 1) ? (float)(nd.w & 255) : (wave_inside ? patch_value_inside(nd.w) : patch_value(nd.w));
                 else v = f == g.pos_depth ? depth_m : (f == g.pos_height ? height : nrm);
                 nd = (v < __int_as_float(nd.y)) ? c0 : c1;
             }
@@ -449,7 +473,7 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
     const int pts_per_block = PPW * WAVES_PER_BLOCK;
     const dim3 grid((unsigned)((total + pts_per_block - 1) / pts_per_block)), block(64 * WAVES_PER_BLOCK);
     static const bool eager = getenv("RVSEG_RF_EAGER") && atoi(getenv("RVSEG_RF_EAGER")) != 0;   // A/B timing only
-    if (!d_dump && !eager && n_trees_ok(f.n_trees) && !g.debug_skip) {
+    if (!d_dump && !eager && n_trees_ok(f.n_trees)) {
         const size_t rt_bytes = (size_t)g.rt_rows * sizeof(ResizeRow);
         const int in_lds = g.n_patch > 0 && rt_bytes <= 40 * 1024 ? 1 : 0;   // else the records come through L1
         rf_frames_lazy_kernel<<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(

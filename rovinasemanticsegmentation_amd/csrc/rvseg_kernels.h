@@ -28,10 +28,10 @@ struct LabCoeffs { int c[9]; };
 // cv::resize coefficient tables of the 8-bit patch path, one row per ROI half size
 // (size = 2*half+1), host-computed with the formula the oracle states (OpenCV 2.4 imgwarp.cpp).
 constexpr int RT_MAXR = 16;
-struct ResizeRec { int16_t ofs, w0, w1, pad; };   // source index, 11-bit weights of (ofs, ofs+1)
+struct ResizeRec { int16_t ofs, w0, w1, ofs1; };   // first tap, 11-bit weights of the two taps, second tap (both inside the ROI)
 struct ResizeRow {
-    ResizeRec x[RT_MAXR];   // x axis: weights clamped at the ROI border
-    ResizeRec y[RT_MAXR];   // y axis: weights kept, rows clipped by the caller
+    ResizeRec x[RT_MAXR];   // x axis: weights clamped at the ROI border (OpenCV's xofs / alpha)
+    ResizeRec y[RT_MAXR];   // y axis: weights kept, the two rows clipped to the ROI (OpenCV's yofs / beta + row clipping)
 };
 
 // float up-sampling tables (cv::resize INTER_LINEAR on CV_32FC(n), segmenter.cpp:380-382)

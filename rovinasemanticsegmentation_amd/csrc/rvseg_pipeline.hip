@@ -81,12 +81,17 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
                 rr.x[d].ofs = (int16_t)ofs[d];
                 rr.x[d].w0 = (int16_t)std::lrintf(w0[d] * 2048.f);  // saturate_cast<short>: round half to even
                 rr.x[d].w1 = (int16_t)std::lrintf(w1[d] * 2048.f);
+                rr.x[d].ofs1 = (int16_t)(ofs[d] + 1 < size ? ofs[d] + 1 : ofs[d]);   // second tap, kept inside the ROI
             }
             resize_coeffs(size, g.r, false, ofs, w0, w1);
             for (int d = 0; d < g.r; d++) {
-                rr.y[d].ofs = (int16_t)ofs[d];
+                // rows are clipped to the ROI (the weights are not): both clipped taps are part of the record
+                const int s0 = ofs[d] < 0 ? 0 : (ofs[d] >= size ? size - 1 : ofs[d]);
+                const int s1 = ofs[d] + 1 < 0 ? 0 : (ofs[d] + 1 >= size ? size - 1 : ofs[d] + 1);
+                rr.y[d].ofs = (int16_t)s0;
                 rr.y[d].w0 = (int16_t)std::lrintf(w0[d] * 2048.f);
                 rr.y[d].w1 = (int16_t)std::lrintf(w1[d] * 2048.f);
+                rr.y[d].ofs1 = (int16_t)s1;
             }
         }
         if ((st = upload(ctx, im->resize_rows, rows.data(), rows.size() * sizeof(ResizeRow))) != RVSEG_OK) return st;
