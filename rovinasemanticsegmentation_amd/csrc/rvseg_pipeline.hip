@@ -225,9 +225,11 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
         if (!im->side) {
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            // highest priority: the build is a chain of many short kernels and must not queue behind the long
-            // feature kernels for CU slots (measured: 13.85 vs 13.98 ms per step)
-            RV_HIP(ctx, hipStreamCreateWithPriority(&im->side, hipStreamNonBlocking, prio_hi));
+            // priority of the build stream.  Round 1 (build = the longer branch) measured the highest priority ahead,
+            // 13.85 vs 13.98 ms per step; since the feature branch is the longer one (5.2 vs 3.6 ms) the lowest is, by
+            // a little: 13.31 / 13.33 vs 13.37 / 13.42 ms (RVSEG_SIDE_PRIO_HIGH=1 restores the old choice)
+            static const int side_high = std::getenv("RVSEG_SIDE_PRIO_HIGH") ? std::atoi(std::getenv("RVSEG_SIDE_PRIO_HIGH")) : 0;
+            RV_HIP(ctx, hipStreamCreateWithPriority(&im->side, hipStreamNonBlocking, side_high ? prio_hi : prio_lo));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_fork, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_join, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreate(&ctx->timer.side0));
