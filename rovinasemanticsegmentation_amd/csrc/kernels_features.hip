@@ -471,6 +471,10 @@ void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_cha
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
                            int n, hipStream_t s) {
     const int tw = NF_TX * g.stride + 2 * NF_APRON, th = NF_TY * g.stride + 2 * NF_APRON;
+    // (A two-half variant -- x planes, then y planes, through one 36.5 KB table, four tiles per CU -- was built and
+    // measured: the kernel's overlapped time fell from 2.0 to 1.2 ms, the lattice build beside it rose from 4.0 to
+    // 5.5 ms and became the critical path: 13.74 vs 13.38 ms per step.  The two branches share the chip work for
+    // work; only less work helps.  Removed.)
     const size_t lds = (size_t)(tw + 1) * (th + 1) * NF_PLANES * 8;
     if (lds <= 80 * 1024) {   // stride <= 2 (73 KB: two tiles per CU); larger strides use the gather kernel
         static bool attr_set[64] = {};   // per device: more than the default 64 KB of dynamic LDS has to be asked for
