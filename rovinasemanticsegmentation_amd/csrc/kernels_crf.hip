@@ -773,6 +773,7 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
     constexpr int AW = (GV < SplatGroup<CC>::G && GV >= 4) ? 3 : GV;   // the adder's wave index
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
+    if (L.skip_if_queue && L.skip_if_queue[0]) return;   // the band-major queue schedule did this splat
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // block b -> XCD group b % n_groups (the dispatcher deals blocks round-robin over the 8 XCDs), item
@@ -932,6 +933,9 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
     else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
 }
 
+template <int CC>
+static void splat_queue_launch(const LatticeDev& L, const SplatQueueDev& q, const ValueView& src, float* values, hipStream_t s);
+
 // RVSEG_SPLAT_GV (timing experiments): 0 = choose by the chunk's shape (default), 6 / 7 = force for C = 8, 9
 static int splat_gv_choice(const LatticeDev& L) {
     static const int forced = std::getenv("RVSEG_SPLAT_GV") ? std::atoi(std::getenv("RVSEG_SPLAT_GV")) : 0;
@@ -941,12 +945,23 @@ static int splat_gv_choice(const LatticeDev& L) {
     return L.n_frames <= 16 ? 6 : 7;
 }
 
-void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q) {
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
+                  const SplatQueueDev* queue) {
     if (mode == 2) {
         splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
+    if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
+        // experimental band-major schedule; the regular launch below stands by and returns at once when the queue is valid
+        splat_queue_launch<9>(L, *queue, src, values, s);
+        LatticeDev L2 = L;
+        L2.skip_if_queue = queue->flags;
+        const int gv = splat_gv_choice(L);
+        if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L2, src, C, 0, 9, values, s);
+        else splat_group_launch_g<0, 9, 7, true>(L2, src, C, 0, 9, values, s);
+        return;
+    }
     if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8)) {
         // the mean-field loop's own input (Q * norm written by the previous update): the fast producer, and the
         // block shape chosen for the chunk
@@ -965,6 +980,240 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         if (mode == 0) splat_group_pass<0>(L, src, C, c0, n, values, s);
         else splat_group_pass<1>(L, src, C, c0, n, values, s);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Band-major work queue (experimental schedule of the ordered splat, RVSEG_SPLAT_QUEUE=1).
+// a vertex-major walk reads every Q row d+1 times at unrelated moments; if all pieces of a
+// frame's lists inside one pixel band are summed at about the same time, the re-reads meet in the XCD's L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void queue_piece(const LatticeDev& L, const SplatQueueDev& q, int f0, int Mf, int lv, int band,
+                                            unsigned& k0, unsigned& k1) {
+    const unsigned* fb = L.bh + (size_t)L.wbpf * f0 + lv;
+    const int w0 = band * q.band_wb, w1 = w0 + q.band_wb;
+    k0 = fb[(size_t)w0 * Mf];
+    k1 = w1 < L.wbpf ? fb[(size_t)w1 * Mf] : L.vend[f0 + lv];
+}
+
+// FILL = false: groups of every (frame, band); FILL = true: the items, longest first, seven to a group
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+queue_items_kernel(LatticeDev L, SplatQueueDev q) {
+    extern __shared__ unsigned qn[];   // piece lengths of the frame's vertices in this band
+    __shared__ unsigned s_cnt;
+    if (L.counters[1]) return;
+    const int frame = blockIdx.x / q.n_bands, band = blockIdx.x - frame * q.n_bands;
+    const int f0 = L.fstart[frame], Mf = L.fstart[frame + 1] - f0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned mine = 0;
+    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
+        unsigned k0, k1;
+        queue_piece(L, q, f0, Mf, lv, band, k0, k1);
+        qn[lv] = k1 - k0;
+        mine += k1 > k0 ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    const int x = frame % q.NQ, slot = frame / q.NQ;
+    const unsigned cell = (unsigned)x * (unsigned)(q.n_bands * q.nfq) + (unsigned)band * q.nfq + slot;
+    const unsigned cnt = s_cnt, groups = (cnt + 6u) / 7u;
+    if (!FILL) {
+        if (threadIdx.x == 0) q.grp_cnt[cell] = groups;
+        return;
+    }
+    if (!q.flags[0]) return;   // more groups than the queue can hold: the regular schedule runs instead
+    QueueItem* out = q.items + ((size_t)q.q_base[x] + q.grp_off[cell]) * 7;
+    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
+        const unsigned n = qn[lv];
+        if (!n) continue;
+        unsigned rank = 0;   // pieces that are longer, or as long with a lower vertex number
+        for (int u = 0; u < Mf; u++) { const unsigned m = qn[u]; rank += (m > n || (m == n && u < lv)) ? 1u : 0u; }
+        unsigned k0, k1;
+        queue_piece(L, q, f0, Mf, lv, band, k0, k1);
+        QueueItem it;
+        it.v = f0 + lv; it.k0 = k0; it.k1 = k1;
+        it.flags = 1u | (k0 == L.vstart[f0 + lv] ? 2u : 0u) | (k1 == L.vend[f0 + lv] ? 4u : 0u);
+        out[q.ascending ? cnt - 1u - rank : rank] = it;
+    }
+    for (unsigned r = cnt + threadIdx.x; r < groups * 7u; r += 256) { QueueItem it; it.v = -1; it.k0 = 0; it.k1 = 0; it.flags = 0; out[r] = it; }
+}
+
+__global__ void __launch_bounds__(64)
+queue_scan_kernel(SplatQueueDev q) {
+    __shared__ unsigned tot[64];
+    const int x = threadIdx.x;
+    if (x < q.NQ) {
+        const unsigned n = (unsigned)(q.n_bands * q.nfq);
+        unsigned run = 0;
+        for (unsigned i = 0; i < n; i++) { const unsigned c = q.grp_cnt[(size_t)x * n + i]; q.grp_off[(size_t)x * n + i] = run; run += c; }
+        tot[x] = run;
+        q.q_total[x] = run;
+    }
+    __syncthreads();
+    if (x == 0) {
+        unsigned run = 0;
+        for (int y = 0; y < q.NQ; y++) { q.q_base[y] = run; run += tot[y]; }
+        q.flags[0] = run <= q.cap_groups ? 1 : 0;
+    }
+}
+
+void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s) {
+    const int mcap = (int)((L.cap_f_mask + 1) / 2);
+    const dim3 grid((unsigned)(L.n_frames * q.n_bands));
+    queue_items_kernel<false><<<grid, dim3(256), (size_t)mcap * 4, s>>>(L, q);
+    queue_scan_kernel<<<dim3(1), dim3(64), 0, s>>>(q);
+    queue_items_kernel<true><<<grid, dim3(256), (size_t)mcap * 4, s>>>(L, q);
+}
+
+// The splat over the queue: a persistent grid; a block takes the next group of its XCD's queue (the queues of the
+// other XCDs once its own is empty), runs the seven pieces exactly like splat_group_kernel runs seven lists --
+// producers form the products of a 64-entry tile, the adder sums them in list order -- and hands every chain on:
+// the adder waits until its vertex has been summed up to the piece's first entry, loads the running sums, and
+// publishes the new position when they are stored.  Sums and positions move with agent-scope (sc1) accesses.
+// Groups are numbered band-major, so whatever a piece waits for has a lower ticket in the same queue and is done or
+// running: the waits cannot deadlock; they are bounded all the same (flags[1] records a time-out).
+// Rings of the queue kernel.  A piece is short (5.5 tiles on average at 4096-pixel bands) and its rows are L2
+// resident after the band's first reader, so shallow rings do; what counts is how many groups a CU holds at once
+// (their start-up latencies -- ticket, descriptors, CSR, rows: three dependent memory round trips -- overlap only
+// across groups): 8 / 4 tiles of look-ahead keep the kernel under 80 VGPRs, i.e. three blocks per CU instead of two.
+constexpr int QRE = 8, QRR = 4;
+static_assert(QRE % QRR == 0, "ring positions are compile-time");
+
+template <int CC>
+__global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64, 6)
+splat_queue_kernel(LatticeDev L, SplatQueueDev q, ValueView src, float* __restrict__ values) {
+    constexpr int G = SplatGroup<CC>::G;
+    constexpr int C = CC;
+    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
+    __shared__ unsigned s_group[2];
+    if (L.counters[1] || !q.flags[0]) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // thread 0 of the block runs the ticket machine: the next group is drawn while the current one is being summed
+    int qq = q.NQ > 1 ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % q.NQ : 0;   // HW_REG_XCC_ID[3:0]; placement is for speed only
+    int tried = 0;
+    auto draw = [&]() -> unsigned {
+        for (; tried < q.NQ; ) {
+            const unsigned t = atomicAdd(&q.head[qq], 1u);
+            if (t < q.q_total[qq]) return q.q_base[qq] + t;
+            tried++;
+            qq = (qq + 1) % q.NQ;
+        }
+        return 0xFFFFFFFFu;
+    };
+    unsigned next_group = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) { next_group = draw(); s_group[0] = next_group; }
+    __syncthreads();
+    for (unsigned round = 0;; round++) {
+        const unsigned group = s_group[round & 1u];
+        if (group == 0xFFFFFFFFu) return;
+        if (threadIdx.x == 0) next_group = draw();   // a returning atomic: waited for only where it is stored, at the end
+        const QueueItem* its = q.items + (size_t)group * 7;
+        const unsigned long long t_pick = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        unsigned n_steps = 0, my_k0 = 0, my_k1 = 0;
+        for (int i = 0; i < G; i++) {
+            const QueueItem it = its[i];
+            const unsigned nt = (it.k1 - it.k0 + 63u) / 64u;
+            n_steps = nt > n_steps ? nt : n_steps;
+            if (i == wave) { my_k0 = it.k0; my_k1 = it.k1; }
+        }
+        if (wave == G) __builtin_amdgcn_s_setprio(3);
+        if (wave < G) {
+            const bool has = my_k1 > my_k0;
+            const unsigned kc0 = has ? my_k0 : 0u, kc1 = has ? my_k1 : 1u;
+            const unsigned n_tiles = has ? (my_k1 - my_k0 + 63u) / 64u : 0u;
+            float x[QRR][CC];
+            float w[QRE];
+            unsigned pix[QRE];
+#pragma unroll
+            for (int r = 0; r < QRE; r++) { w[r] = 0.f; pix[r] = 0u; }
+            auto load_entries = [&](unsigned tile, int slot) {
+                unsigned k = kc0 + tile * 64u + lane;
+                k = k < kc1 ? k : kc1 - 1u;
+                const uint2 pw = L.csr_pw[k];
+                w[slot] = __uint_as_float(pw.y);
+                pix[slot] = pw.x;
+            };
+            auto gather_rows = [&](int eslot, int rslot) { load_row<CC>(src.base + (size_t)pix[eslot] * (unsigned)C, x[rslot]); };
+#pragma unroll
+            for (int i = 0; i < QRE - 1; i++) load_entries((unsigned)i, i);
+#pragma unroll
+            for (int i = 0; i < QRR - 1; i++) gather_rows(i, i);
+            auto stage = [&](unsigned t, auto S) -> bool {
+                constexpr int s = decltype(S)::value;
+                if (t >= n_steps) return false;
+                const unsigned base = my_k0 + t * 64u;
+                const unsigned n_valid = t < n_tiles ? (my_k1 - base < 64u ? my_k1 - base : 64u) : 0u;
+                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
+                float (*pb)[68] = prod[t & 1u][wave];
+#pragma unroll
+                for (int c = 0; c < CC; c++) pb[c][lane] = wl * x[s % QRR][c];   // +0 past the piece (finite rows)
+                load_entries(t + QRE - 1, (s + QRE - 1) % QRE);
+                gather_rows((s + QRR - 1) % QRE, (s + QRR - 1) % QRR);
+                __syncthreads();
+                return true;
+            };
+#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
+            for (unsigned t0 = 0;; t0 += QRE) {
+                RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
+            }
+#undef RV_ST
+            __syncthreads();
+        } else {
+            const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
+            const QueueItem it = its[gi];
+            const bool mine = lane < G * CC && (it.flags & 1u);
+            const unsigned my_tiles = mine ? (it.k1 - it.k0 + 63u) / 64u : 0u;
+            // the chain travels as one 8-byte granule per (vertex, class): {running sum, list position it is valid for},
+            // written by ONE sc1 store and polled by ONE sc1 load -- data and flag cannot be seen apart
+            unsigned long long* gran = q.vacc + ((size_t)(mine ? it.v : 0) * C + c);
+            float acc = 0.0f;
+            if (mine && !(it.flags & 2u)) {
+                unsigned spins = 0;
+                for (;;) {
+                    const unsigned long long gval = __hip_atomic_load(gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(gval >> 32) == it.k0) { acc = __uint_as_float((unsigned)gval); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 17)) { q.flags[1] = 1; break; }
+                }
+            }
+            const unsigned long long t_deps = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            __syncthreads();
+            const unsigned long long t_go = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            for (unsigned t = 0; t < n_steps; t++) {
+                const float* pr = prod[t & 1u][gi][c];
+                float4 qv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) qv[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                for (int i = 0; i < 16; i++) { acc += qv[i].x; acc += qv[i].y; acc += qv[i].z; acc += qv[i].w; }
+                if (q.trace && lane == 0 && t + 1u == n_steps) {
+                    unsigned long long* tr = q.trace + (size_t)group * 4;
+                    tr[0] = t_pick; tr[1] = t_deps; tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = ((unsigned long long)n_steps << 32) | (unsigned)(t_go - t_deps);
+                }
+                if (t + 1u == my_tiles) {
+                    // this piece is complete (shorter pieces of the group do not wait for the longest): hand the chain on
+                    __hip_atomic_store(gran, ((unsigned long long)it.k1 << 32) | (unsigned long long)__float_as_uint(acc),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (it.flags & 4u) values[(size_t)it.v * C + c] = acc;   // the vertex's last piece: the blur reads `values`
+                }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) s_group[(round + 1u) & 1u] = next_group;
+        __syncthreads();   // the product buffers are free again, the next group is known
+    }
+}
+
+template <int CC>
+static void splat_queue_launch(const LatticeDev& L, const SplatQueueDev& q, const ValueView& src, float* values, hipStream_t s) {
+    constexpr int G = SplatGroup<CC>::G;
+    static const int per_cu = std::getenv("RVSEG_SPLAT_QUEUE_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_BLOCKS_PER_CU")) : 3;
+    (void)hipMemsetAsync(q.head, 0, 64 * sizeof(unsigned), s);
+    // vertices without entries (the lattice's padding points create some) get no piece: their sums are the zeros below
+    (void)hipMemsetAsync(values, 0, (size_t)L.m_bound * CC * sizeof(float), s);   // (granule tags of earlier launches are harmless: no piece of this one waits for a position an earlier launch left behind)
+    splat_queue_kernel<CC><<<dim3((unsigned)(256 * per_cu)), dim3((G + 1) * 64), 0, s>>>(L, q, src, values);
 }
 
 int csr_pix_per_block() { return CS_PIX; }

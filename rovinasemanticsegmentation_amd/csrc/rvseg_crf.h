@@ -41,6 +41,28 @@ struct LatticeDev {
     int wbpf;                    // wave-blocks per frame
     int n_bands, band_wb;        // bands per frame (1 = whole lists) and wave-blocks per band
     float* norm;                 // per point, pairwise.cpp:55-56
+    const int* skip_if_queue;    // non-null: this launch only runs when the band-major queue could not be built ([0] == 0)
+};
+
+// Band-major work queue of the ordered splat (experimental schedule, RVSEG_SPLAT_QUEUE=1).  Every vertex list is cut
+// at multiples of `band_wb` wave-blocks of 256 points; the pieces of a (frame, band) are sorted by length and packed
+// seven to a group; queue x holds the groups of the frames f = x (mod NQ), band after band.  A piece continues the
+// fp32 chain of its vertex where the previous piece stopped: the running sums travel through `values`, `vprog[v]` is
+// the list position up to which vertex v has been summed.
+struct QueueItem { int v; unsigned k0, k1; unsigned flags; };   // flags: 1 = valid, 2 = first piece of its vertex, 4 = last
+struct SplatQueueDev {
+    QueueItem* items;       // groups of 7 items; queue x starts at group q_base[x]
+    unsigned* grp_cnt;      // [NQ][n_bands * nfq]: groups of (band, frame slot)
+    unsigned* grp_off;      // exclusive scan of grp_cnt inside a queue
+    unsigned* q_total;      // [NQ]
+    unsigned* q_base;       // [NQ]
+    unsigned* head;         // [NQ] tickets of the running launch (zeroed before it)
+    unsigned long long* vacc;   // [m_bound][C <= 16] granules {running sum bits, list position}
+    int* flags;             // [0] queue valid (built without exceeding cap_groups), [1] a dependency wait timed out
+    int band_wb, n_bands, nfq, NQ;
+    unsigned long long* trace;   // optional (RVSEG_SPLAT_QUEUE_TRACE=1): per group {picked, dependencies met, done} in 10 ns ticks + steps
+    int ascending;          // order of a (frame, band)'s pieces inside the queue: shortest first (1) or longest first (0)
+    unsigned cap_groups;
 };
 
 // Where the lattice features come from.
@@ -88,7 +110,10 @@ int csr_pix_per_block();
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 // own_q: src is the mean-field loop's own Q * norm (finite, non-negative): enables the select-free producer
-void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q = false);
+void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q = false,
+                  const SplatQueueDev* queue = nullptr);
+// builds the band-major queue from the counting-sort table (after launch_lattice_finish)
+void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s);
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks = false);
 // out_mode 0: plain, 1: normaliser, 2: inference update (tmp -= (-w) * (sliced * norm))
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,

@@ -14,6 +14,9 @@ namespace rvseg {
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pw, csr_nrm, vstart, vend, norm;
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, block_hist;
+    DevBuf q_items, q_cnt, q_off, q_small, q_vprog, q_trace;   // band-major splat queue (RVSEG_SPLAT_QUEUE=1)
+    SplatQueueDev queue{};
+    bool queue_on = false;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -51,7 +54,8 @@ static rvseg_status crf_state(rvseg_ctx* ctx, Pipeline* im, CrfState** out) {
 static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
-                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist};
+                     &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist,
+                     &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -172,6 +176,37 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     }
     b.n_entries = E; b.n_points = P;
     b.built = false;
+    // experimental band-major queue schedule of the splat
+    const int queue_env = std::getenv("RVSEG_SPLAT_QUEUE") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE")) : 0;
+    b.queue_on = false;
+    if (queue_env && L.bh && d == 6) {
+        const int band_env = std::getenv("RVSEG_SPLAT_QUEUE_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_BAND")) : 16;
+        SplatQueueDev& q = b.queue;
+        q.band_wb = band_env < 1 ? 1 : band_env;
+        const int asc_env = std::getenv("RVSEG_SPLAT_QUEUE_ASC") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_ASC")) : 0;
+        q.ascending = asc_env;
+        q.n_bands = (L.wbpf + q.band_wb - 1) / q.band_wb;
+        q.NQ = L.n_groups;
+        q.nfq = (n_frames + q.NQ - 1) / q.NQ;
+        q.cap_groups = (unsigned)std::min<unsigned long long>((unsigned long long)n_frames * q.n_bands * 64ull, 1ull << 24);
+        const size_t cells = (size_t)q.NQ * q.n_bands * q.nfq;
+        if ((st = dev_reserve(ctx, b.q_items, (size_t)q.cap_groups * 7 * sizeof(QueueItem))) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, b.q_cnt, cells * 4)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, b.q_off, cells * 4)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, b.q_small, 4 * 64 * 4)) != RVSEG_OK) return st;
+        if ((st = dev_reserve(ctx, b.q_vprog, (size_t)m_bound * 16 * 8)) != RVSEG_OK) return st;
+        q.items = b.q_items.as<QueueItem>();
+        q.grp_cnt = b.q_cnt.as<unsigned>(); q.grp_off = b.q_off.as<unsigned>();
+        q.q_total = b.q_small.as<unsigned>(); q.q_base = q.q_total + 64; q.head = q.q_total + 128;
+        q.flags = reinterpret_cast<int*>(q.q_total + 192);
+        q.vacc = b.q_vprog.as<unsigned long long>();
+        q.trace = nullptr;
+        if (std::getenv("RVSEG_SPLAT_QUEUE_TRACE")) {
+            if ((st = dev_reserve(ctx, b.q_trace, (size_t)q.cap_groups * 32)) != RVSEG_OK) return st;
+            q.trace = b.q_trace.as<unsigned long long>();
+        }
+        b.queue_on = true;
+    }
     return RVSEG_OK;
 }
 
@@ -200,6 +235,12 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     tr("points");
     launch_lattice_finish(L, b.sb, b.n_entries, s);
     tr("finish");
+    if (b.queue_on) {
+        RV_HIP(ctx, hipMemsetAsync(b.q_small.p, 0, 4 * 64 * 4, s));
+        RV_HIP(ctx, hipMemsetAsync(b.q_vprog.p, 0xFF, (size_t)L.m_bound * 16 * 8, s));
+        launch_queue_build(L, b.queue, s);
+        tr("queue");
+    }
     rvseg_status st = values_reserve(ctx, cs, L.m_bound, 1);
     if (st != RVSEG_OK) return st;
     // norm = lattice.compute(ones) through seqCompute (1 row), then 1/sqrt(norm + 1e-20)
@@ -288,7 +329,7 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             const LatticeBufs& b = cs->lat[0];
             const bool seq = C <= 2;
             mark("splat");
-            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused);
+            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused, (b.queue_on && slot == 0) ? &b.queue : nullptr);
             mark("blur");
             float* blurred = launch_blur(b.dev, C, seq, false, b_va.as<float>(), b_vb.as<float>(), s);
             if (fused) {
@@ -673,6 +714,25 @@ rvseg_status rvseg_lattice_neighbours(rvseg_ctx* ctx, int32_t* n1_out, int32_t* 
     }
     if (vstart) RV_HIP(ctx, hipMemcpy(vstart, lb.dev.vstart, (size_t)M * 4, hipMemcpyDeviceToHost));
     if (vend) RV_HIP(ctx, hipMemcpy(vend, lb.dev.vend, (size_t)M * 4, hipMemcpyDeviceToHost));
+    return RVSEG_OK;
+}
+
+// debug (not in rvseg.h): the queue of the frame path's last lattice: items (16 B each), per-cell group offsets, trace
+rvseg_status rvseg_debug_queue(rvseg_ctx* ctx, void* items_out, size_t items_cap, unsigned* n_groups_total, unsigned* q_base8, unsigned* q_total8,
+                               unsigned long long* trace_out, int* meta /* band_wb, n_bands, nfq, NQ */) {
+    if (!ctx || !ctx->impl) return RVSEG_ERR_INVALID_ARG;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    if (!im->crf || im->crf->lat.empty() || !im->crf->lat[0].queue_on) return RVSEG_ERR_INVALID_ARG;
+    LatticeBufs& b = im->crf->lat[0];
+    RV_HIP(ctx, hipDeviceSynchronize());
+    unsigned small[256];
+    RV_HIP(ctx, hipMemcpy(small, b.q_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    unsigned tot = 0;
+    for (int x = 0; x < b.queue.NQ; x++) { q_base8[x] = small[64 + x]; q_total8[x] = small[x]; tot += small[x]; }
+    *n_groups_total = tot;
+    meta[0] = b.queue.band_wb; meta[1] = b.queue.n_bands; meta[2] = b.queue.nfq; meta[3] = b.queue.NQ;
+    if (items_out && items_cap >= (size_t)tot * 7 * 16) RV_HIP(ctx, hipMemcpy(items_out, b.q_items.p, (size_t)tot * 7 * 16, hipMemcpyDeviceToHost));
+    if (trace_out && b.queue.trace) RV_HIP(ctx, hipMemcpy(trace_out, b.q_trace.p, (size_t)tot * 32, hipMemcpyDeviceToHost));
     return RVSEG_OK;
 }
 

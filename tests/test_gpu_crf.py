@@ -208,3 +208,30 @@ def test_ten_small_frames_uneven_xcd_groups(gpu_ctx_factory, oracle):
         assert np.array_equal(out["posteriors"][i], post), i
         assert np.array_equal(out["marginals"][i], marg), i
         assert np.array_equal(out["labels"][i].ravel(), lab), i
+
+
+@pytest.mark.parametrize("band", [1, 4, 64])
+def test_queue_splat_is_bit_exact_too(gpu_ctx_factory, oracle, band):
+    """RVSEG_SPLAT_QUEUE=1: the band-major work-queue schedule of the ordered splat -- every vertex
+    list cut into pixel bands, the pieces regrouped per band and run by a persistent grid, chains handed from piece to
+    piece through 8-byte {sum, position} granules.  Each chain is still summed in ascending point order, so nothing
+    may change.  Bands of 1 / 4 / 64 wave-blocks: many tiny pieces, a few per list, (nearly) whole lists."""
+    blob = synthetic.make_forest_bytes(seed=24, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
+    forest = oracle.Forest(blob)
+    W, H = 320, 240
+    rgb, depth = synthetic.make_batch(9, W, H, holes=True, start=2)     # 9 frames: uneven XCD queues
+    calib = synthetic.make_calib(W, H)
+    os.environ["RVSEG_SPLAT_QUEUE"] = "1"
+    os.environ["RVSEG_SPLAT_QUEUE_BAND"] = str(band)
+    try:
+        ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=3, label_mode=1, unknown_label=[8], max_batch=16)
+        ctx.forest_load(blob)
+        out = ctx.segment_frames(rgb, depth, calib)
+    finally:
+        del os.environ["RVSEG_SPLAT_QUEUE"]
+        del os.environ["RVSEG_SPLAT_QUEUE_BAND"]
+    p = oracle.default_params(width=W, height=H, dcrf_iterations=3)
+    for i in range(9):
+        post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
+        assert np.array_equal(out["marginals"][i], marg), i
+        assert np.array_equal(out["labels"][i].ravel(), lab), i
