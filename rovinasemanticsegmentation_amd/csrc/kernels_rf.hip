@@ -167,7 +167,7 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
     __syncthreads();
 
     // ---- phase B: Lab patch, cv::resize(ROI -> r x r) in 11-bit fixed point (feature_extractor.h:142)
-    if (g.n_patch > 0 && !(g.debug_skip & 1)) {
+    if (g.n_patch > 0) {
         const int rr = g.r * g.r;
         for (int k0 = 0; k0 < rr; k0 += 64) {
             const int k = k0 + lane;
@@ -239,7 +239,7 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
     const int4* np = reinterpret_cast<const int4*>(nodes);
     for (int t = sub; t < n_trees; t += 4) {
         int row = 0;
-        if (valid && !(g.debug_skip & 2)) {
+        if (valid) {
             int4 nd = np[roots[t]];
             while (nd.z != 0) {
                 const int f = nd.x;
@@ -404,7 +404,7 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
                 const int4 c0 = np[nd.z], c1 = np[nd.z + 1];
                 const int f = nd.x;
                 float v;
-                if (f < g.n_patch) v = (g.debug_skip & 1) ? (float)(nd.w & 255) : (wave_inside ? patch_value_inside(nd.w) : patch_value(nd.w));
+                if (f < g.n_patch) v = wave_inside ? patch_value_inside(nd.w) : patch_value(nd.w);
                 else v = f == g.pos_depth ? depth_m : (f == g.pos_height ? height : nrm);
                 nd = (v < __int_as_float(nd.y)) ? c0 : c1;
             }

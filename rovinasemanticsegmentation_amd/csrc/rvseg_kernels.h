@@ -19,7 +19,6 @@ struct FrameGeom {
     int pos_depth, pos_height, pos_normal; // index of each scalar feature in the vector or -1
     int D;                      // feature length
     float fill;                 // low-res image fill value
-    int debug_skip;             // RVSEG_DEBUG_SKIP (timing experiments only): 1 = no patch, 2 = no traversal
     int rt_rows;                // rows of the ResizeRow table (largest ROI half size + 1), 0 without colour patch
 };
 

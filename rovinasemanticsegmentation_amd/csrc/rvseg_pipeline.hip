@@ -63,7 +63,6 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
     g.pos_normal = p.feature_normal ? pos++ : -1;
     g.D = pos;
     g.fill = p.fill_value;
-    g.debug_skip = std::getenv("RVSEG_DEBUG_SKIP") ? std::atoi(std::getenv("RVSEG_DEBUG_SKIP")) : 0;
     g.rt_rows = 0;
 
     rvseg_status st;
