@@ -945,13 +945,25 @@ static int splat_gv_choice(const LatticeDev& L) {
     return L.n_frames <= 16 ? 6 : 7;
 }
 
+static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s);
+
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
-                  const SplatQueueDev* queue) {
+                  const SplatQueueDev* queue, const SplatResidentDev* resident, int slot) {
     if (mode == 2) {
         splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
+    if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && resident) {
+        // resident band schedule; the list-major launch behind it returns at once unless the planner gave up
+        splat_resident_launch(L, *resident, src.base, values, slot, s);
+        LatticeDev L2 = L;
+        L2.skip_if_queue = resident->flags + 1;
+        const int gv = splat_gv_choice(L);
+        if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L2, src, C, 0, 9, values, s);
+        else splat_group_launch_g<0, 9, 7, true>(L2, src, C, 0, 9, values, s);
+        return;
+    }
     if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
         // experimental band-major schedule; the regular launch below stands by and returns at once when the queue is valid
         splat_queue_launch<9>(L, *queue, src, values, s);
@@ -1214,6 +1226,384 @@ static void splat_queue_launch(const LatticeDev& L, const SplatQueueDev& q, cons
     // vertices without entries (the lattice's padding points create some) get no piece: their sums are the zeros below
     (void)hipMemsetAsync(values, 0, (size_t)L.m_bound * CC * sizeof(float), s);   // (granule tags of earlier launches are harmless: no piece of this one waits for a position an earlier launch left behind)
     splat_queue_kernel<CC><<<dim3((unsigned)(256 * per_cu)), dim3((G + 1) * 64), 0, s>>>(L, q, src, values);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resident band schedule of the ordered splat (SplatResidentDev, rvseg_crf.h).
+// ---------------------------------------------------------------------------------------------
+// piece of frame-local vertex lv inside band b: [k0, k1) of its list
+__device__ __forceinline__ void resident_piece(const LatticeDev& L, int band_wb, int f0, int Mf, int lv, int b, unsigned& k0, unsigned& k1) {
+    const unsigned* fb = L.bh + (size_t)L.wbpf * f0 + lv;
+    const int w0 = b * band_wb, w1 = w0 + band_wb;
+    k0 = fb[(size_t)w0 * Mf];
+    k1 = w1 < L.wbpf ? fb[(size_t)w1 * Mf] : L.vend[f0 + lv];
+}
+
+// One block per frame: 64-entry chunks of every vertex (summed over the bands), vertices dealt to the B blocks
+// (longest first, each to the block with the fewest chunks so far), tiles of every (block, band), tile numbers.
+__global__ void __launch_bounds__(256)
+resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
+    __shared__ unsigned chv[RES_MAX_VERTS];
+    __shared__ unsigned short own[RES_MAXB][RES_MAX_OWNV];
+    __shared__ unsigned nown[RES_MAXB];
+    __shared__ unsigned T[RES_MAXB][RES_MAX_BANDS];
+    __shared__ unsigned blk0[RES_MAXB + 1];
+    __shared__ int bad;
+    if (L.counters[1]) return;
+    const int frame = blockIdx.x;
+    const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int f0 = L.fstart[frame] < Mtot ? L.fstart[frame] : Mtot;
+    const int f1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
+    const int Mf = f1 - f0, nb = R.n_bands, B = R.B;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if (Mf > RES_MAX_VERTS) {
+        if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1);
+        return;
+    }
+    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
+        unsigned k0, k1, ch = 0;
+        resident_piece(L, R.band_wb, f0, Mf, lv, 0, k0, k1);
+        for (int b = 0; b < nb; b++) {
+            ch += (k1 - k0 + 63u) >> 6;
+            k0 = k1;
+            if (b + 1 < nb) { unsigned a; resident_piece(L, R.band_wb, f0, Mf, lv, b + 1, a, k1); }
+        }
+        chv[lv] = ch;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned load[RES_MAXB];
+        for (int j = 0; j < B; j++) { load[j] = 0; nown[j] = 0; }
+        for (int k = 0; k < Mf; k++) {
+            const int lv = (int)L.vorder[f0 + k] - f0;
+            int best = -1;
+            for (int j = 0; j < B; j++) if (nown[j] < (unsigned)RES_MAX_OWNV && (best < 0 || load[j] < load[best])) best = j;
+            if (best < 0 || lv < 0 || lv >= Mf) { bad = 1; break; }
+            load[best] += chv[lv] + 1u;
+            own[best][nown[best]++] = (unsigned short)lv;
+        }
+    }
+    __syncthreads();
+    if (bad) { if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1); return; }
+    for (int idx = threadIdx.x; idx < B * nb; idx += 256) {
+        const int j = idx / nb, b = idx - j * nb;
+        unsigned sum = 0, mx = 0;
+        for (unsigned u = 0; u < nown[j]; u++) {
+            unsigned k0, k1;
+            resident_piece(L, R.band_wb, f0, Mf, own[j][u], b, k0, k1);
+            const unsigned ch = (k1 - k0 + 63u) >> 6;
+            sum += ch;
+            mx = ch > mx ? ch : mx;
+        }
+        const unsigned t = (sum + 6u) / 7u;
+        T[j][b] = t > mx ? t : mx;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < B) {
+        unsigned run = 0;
+        for (int b = 0; b < nb; b++) { const unsigned t = T[threadIdx.x][b]; T[threadIdx.x][b] = run; run += t; }
+        blk0[threadIdx.x + 1] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk0[0] = 0;
+        for (int j = 0; j < B; j++) blk0[j + 1] += blk0[j];
+        if (blk0[B] > R.cap_tiles) bad = 1;
+    }
+    __syncthreads();
+    if (bad) { if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1); return; }
+    unsigned* jb = R.jb_tile + (size_t)frame * RES_MAXB * (nb + 1);
+    for (int idx = threadIdx.x; idx < B * (nb + 1); idx += 256) {
+        const int j = idx / (nb + 1), b = idx - j * (nb + 1);
+        jb[idx] = b < nb ? blk0[j] + T[j][b] : blk0[j + 1];
+    }
+    for (int j = threadIdx.x; j <= B; j += 256) R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j] = blk0[j];
+    for (int j = threadIdx.x; j < B; j += 256) R.blk_nown[(size_t)frame * RES_MAXB + j] = nown[j];
+    for (int idx = threadIdx.x; idx < B * RES_MAX_OWNV; idx += 256) {
+        const int j = idx / RES_MAX_OWNV, u = idx - j * RES_MAX_OWNV;
+        R.blk_verts[((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV + u] = (unsigned)u < nown[j] ? own[j][u] : (unsigned short)0;
+    }
+}
+
+__global__ void resident_seal_kernel(LatticeDev L, SplatResidentDev R) {
+    R.flags[1] = (R.flags[0] == 0 && L.counters[1] == 0) ? 1 : 0;
+}
+
+// One thread per (block, band): packs the chunks of the block's vertices into the band's T tiles x 7 slots by the
+// wrap-around rule -- the cells are filled slot after slot, a vertex that does not fit the rest of a slot continues at
+// the top of the next one; because a vertex has at most T chunks the two parts never share a tile, and its chunks
+// are numbered by tile, so they are summed in list order whatever slot they sit in.
+__global__ void __launch_bounds__(64)
+resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
+    if (!R.flags[1]) return;
+    const int frame = blockIdx.y;
+    const int nb = R.n_bands, B = R.B;
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= B * nb) return;
+    const int j = idx / nb, b = idx - j * nb;
+    const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int f0 = L.fstart[frame] < Mtot ? L.fstart[frame] : Mtot;
+    const int f1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
+    const int Mf = f1 - f0;
+    const unsigned* jb = R.jb_tile + ((size_t)frame * RES_MAXB + j) * (nb + 1);
+    const unsigned t0 = jb[b], T = jb[b + 1] - t0;
+    if (!T) return;
+    const unsigned n_own = R.blk_nown[(size_t)frame * RES_MAXB + j];
+    const unsigned short* verts = R.blk_verts + ((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV;
+    const unsigned base = (unsigned)frame * (unsigned)L.N * 7u;   // the frame's first entry (csr_scan_kernel)
+    unsigned* info = R.tinfo + (size_t)frame * R.cap_tiles + t0;
+    for (unsigned t = 0; t < T; t++) info[t] = (unsigned)b << 16;
+    unsigned slot = 0, x = 0;        // next free cell
+    unsigned any_k0 = 0xFFFFFFFFu;   // an entry of this band: what an unused cell points at (weight 0)
+    auto cell = [&](unsigned s, unsigned t, unsigned u, unsigned at, unsigned n) {
+        R.tdesc[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = ((at - base) << 7) | n;
+        R.tvl[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = (unsigned short)u;
+        const unsigned cur = info[t];
+        if ((cur & 255u) < n) info[t] = (cur & ~255u) | n;
+    };
+    for (unsigned u = 0; u < n_own; u++) {
+        unsigned k0, k1;
+        resident_piece(L, R.band_wb, f0, Mf, verts[u], b, k0, k1);
+        const unsigned len = k1 - k0, ch = (len + 63u) >> 6;
+        if (!ch) continue;
+        if (any_k0 == 0xFFFFFFFFu) any_k0 = k0;
+        const unsigned room = T - x;            // cells left in this slot
+        const unsigned wrap = ch > room ? ch - room : 0u;   // chunks that go to the top of the next slot: the FIRST ones (lower tiles)
+        for (unsigned q = 0; q < ch; q++) {
+            const unsigned n = len - 64u * q < 64u ? len - 64u * q : 64u;
+            if (q < wrap) cell(slot + 1u, q, u, k0 + 64u * q, n);
+            else cell(slot, x + (q - wrap), u, k0 + 64u * q, n);
+        }
+        if (wrap) { slot++; x = wrap; }
+        else { x += ch; if (x == T) { slot++; x = 0; } }
+    }
+    for (; slot < 7u; slot++, x = 0)
+        for (; x < T; x++) cell(slot, x, n_own, any_k0, 0u);
+}
+
+void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStream_t s) {
+    (void)hipMemsetAsync(R.flags, 0, 2 * sizeof(int), s);
+    resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(256), 0, s>>>(L, R);
+    resident_seal_kernel<<<dim3(1), dim3(1), 0, s>>>(L, R);
+    resident_fill_kernel<<<dim3((unsigned)((R.B * R.n_bands + 63) / 64), (unsigned)L.n_frames), dim3(64), 0, s>>>(L, R);
+}
+
+// The splat over the schedule.  Block (frame, j): 7 producer waves + the adder, as in splat_group_kernel; the tile
+// list replaces the walk down seven whole lists.  Producer i reads the descriptor stream of slot i 64 tiles at a time
+// into one register (lane = tile), refreshed once per unrolled group of stages with an unconditional load, so the
+// stage bodies index it with compile-time lanes and the loads of entries (RE - 1 tiles ahead) and rows (RR - 1 tiles
+// ahead) run on across vertices and bands without a bubble.  The adder's lane (i, c) serves whatever vertex slot i
+// holds in the tile: the running sums of the block's vertices sit in LDS, and a lane swaps its sum when the slot's
+// vertex changes (store, then load: one wave, so a chain that moves to another slot in the next tile is handed over
+// in order).  Pacing: at the first tile of a band the adder publishes the band and holds the block (by arriving late
+// at the tile's barrier) while any block of its frame is more than `window` bands behind; the check uses the progress
+// words fetched one band earlier, so it costs no round trip unless it waits, and the wait is bounded -- blocks never
+// depend on each other for their results.
+template <int CC, int RE, int RR>
+__global__ void __launch_bounds__(512)
+splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* __restrict__ values, unsigned tag, int slot) {
+    constexpr int G = 7, C = CC;
+    static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
+    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
+    __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
+    if (L.counters[1] || !R.flags[1]) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // block b -> XCD b % NG; all B blocks of a frame on one XCD (frame f lives on XCD f % NG)
+    const unsigned NG = (unsigned)L.n_groups, B = (unsigned)R.B;
+    const unsigned x = blockIdx.x % NG, jj = blockIdx.x / NG;
+    const unsigned j = jj % B, frame = (jj / B) * NG + x;
+    if (frame >= (unsigned)L.n_frames) return;
+    const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    const int f0 = L.fstart[frame] < Mtot ? L.fstart[frame] : Mtot;
+    const unsigned tb = R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j], te = R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j + 1];
+    const unsigned n_t = te - tb;
+    const unsigned n_own = R.blk_nown[(size_t)frame * RES_MAXB + j];
+    for (unsigned e = threadIdx.x; e < (n_own + 1u) * CC; e += 512) accs[e] = 0.0f;
+    unsigned* prog = R.prog + ((size_t)slot * L.n_frames + frame) * RES_MAXB;
+    const unsigned long long t_start = R.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long t_spin = 0;
+    if (wave == G) __builtin_amdgcn_s_setprio(3);
+    else if (n_t > 256u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+    if (wave < G) {
+        if (n_t) {
+            const unsigned* D = R.tdesc + ((size_t)frame * 7 + wave) * R.cap_tiles + tb;
+            const unsigned base = frame * (unsigned)L.N * 7u;   // the frame's first entry (csr_scan_kernel: every point has d + 1 entries)
+            const unsigned klast = base + (unsigned)L.N * 7u - 1u;
+            float xr[RR][CC];
+            float w[RE];
+            unsigned pix[RE];
+#pragma unroll
+            for (int r = 0; r < RE; r++) { w[r] = 0.f; pix[r] = 0u; }
+            auto load_desc = [&](unsigned first) -> unsigned {
+                const unsigned t = first + (unsigned)lane;
+                return D[t < n_t ? t : n_t - 1u];
+            };
+            unsigned dcur = load_desc(0u), dnxt = dcur;
+            auto load_entries = [&](unsigned d, int slot_e) {
+                const unsigned n = d & 127u, last = n ? n - 1u : 0u;
+                unsigned k = base + (d >> 7) + ((unsigned)lane < last ? (unsigned)lane : last);
+                k = k < klast ? k : klast;
+                const uint2 e = L.csr_pw[k];
+                w[slot_e] = __uint_as_float(e.y);
+                pix[slot_e] = e.x;
+            };
+            // (the rows come through a plain pointer: a const __restrict__ kernel argument makes the gathers invariant loads,
+            // which the compiler then sinks to their use -- the whole prefetch distance lost)
+            auto gather_rows = [&](int eslot, int rslot) { load_row<CC>(srcv.base + (size_t)pix[eslot] * (unsigned)C, xr[rslot]); };
+#pragma unroll
+            for (int i = 0; i < RE - 1; i++) load_entries(__builtin_amdgcn_readlane(dcur, i), i);
+#pragma unroll
+            for (int i = 0; i < RR - 1; i++) gather_rows(i, i);
+            auto stage = [&](unsigned t, auto S) -> bool {
+                constexpr int s = decltype(S)::value;
+                if (t >= n_t) return false;
+                const unsigned n = __builtin_amdgcn_readlane(dcur, s) & 127u;
+                const float wl = (unsigned)lane < n ? w[s] : 0.0f;
+                float (*pb)[68] = prod[t & 1u][wave];
+#pragma unroll
+                for (int c = 0; c < CC; c++) pb[c][lane] = wl * xr[s % RR][c];   // +0 past the chunk (rows are finite)
+                load_entries(__builtin_amdgcn_readlane(dcur, s + RE - 1), (s + RE - 1) % RE);
+                gather_rows((s + RR - 1) % RE, (s + RR - 1) % RR);
+                __syncthreads();
+                return true;
+            };
+#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
+            for (unsigned t0 = 0;; t0 += RE) {
+                dnxt = load_desc(t0 + RE);   // lanes 0 .. 2 RE - 2 of the next group's register
+                RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
+                if constexpr (RE == 16) {
+                    RV_ST(8) RV_ST(9) RV_ST(10) RV_ST(11) RV_ST(12) RV_ST(13) RV_ST(14) RV_ST(15)
+                }
+                dcur = dnxt;
+            }
+#undef RV_ST
+        }
+        __syncthreads();
+    } else {
+        const bool live = lane < G * CC;
+        const int gi = live ? lane / CC : 0;
+        const int c = live ? lane % CC : 0;
+        const unsigned* I = R.tinfo + (size_t)frame * R.cap_tiles + tb;
+        const unsigned short* V = R.tvl + ((size_t)frame * 7 + gi) * R.cap_tiles + tb;
+        auto load_info = [&](unsigned first) -> unsigned {
+            const unsigned t = first + (unsigned)lane;
+            return n_t ? I[t < n_t ? t : n_t - 1u] : 0u;
+        };
+        auto load_vl = [&](unsigned t) -> unsigned { return (live && t < n_t) ? (unsigned)V[t] : n_own; };
+        auto poll = [&]() -> unsigned { return __hip_atomic_load(&prog[(unsigned)lane < B ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const unsigned tagv = tag << 16;
+        if (lane == 0) __hip_atomic_store(&prog[j], n_t ? tagv : (tagv | 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned icur = 0u, inxt = load_info(0u);
+        unsigned polled = poll();
+        unsigned vl[4] = {load_vl(0u), load_vl(1u), load_vl(2u), load_vl(3u)};   // the slot's vertex, four tiles ahead
+        unsigned cur_vl = n_own, cur_band = 0u;
+        bool pacing = R.window >= 0;
+        float acc = 0.0f;
+        __syncthreads();
+        auto tile = [&](unsigned t, auto S) -> bool {
+            constexpr int s = decltype(S)::value;
+            if (t >= n_t) return false;
+            if ((t & 63u) == 0u) { icur = inxt; inxt = load_info(t + 64u); }
+            const unsigned info = __builtin_amdgcn_readlane(icur, (int)(t & 63u));
+            const unsigned nmax = info & 255u, band = info >> 16;
+            const unsigned v = vl[s];
+            vl[s] = load_vl(t + 4u);
+            if (v != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v * CC + c]; cur_vl = v; }
+            if (band != cur_band) {
+                cur_band = band;
+                if (lane == 0) __hip_atomic_store(&prog[j], tagv | band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pacing) {
+                    auto behind = [&](unsigned pv) -> bool {
+                        // a word of another launch: that block has not started yet
+                        return (unsigned)lane < B && ((pv >> 16) != tag || (pv & 0xFFFFu) + (unsigned)R.window < band);
+                    };
+                    if (__ballot(behind(polled))) {
+                        const unsigned long long ts = R.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                        unsigned spins = 0;
+                        for (;;) {
+                            polled = poll();
+                            if (!__ballot(behind(polled))) break;
+                            if (++spins > 256u) { pacing = false; break; }   // some block is not running: stop waiting for good
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (R.trace) t_spin += __builtin_amdgcn_s_memrealtime() - ts;
+                    }
+                    polled = poll();   // consumed at the next band
+                }
+            }
+            const float* pr = prod[t & 1u][gi][c];
+            if (nmax > 32u) {
+                float4 q[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+            } else if (nmax > 16u) {
+                float4 q[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+            } else {
+                float4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+            }
+            __syncthreads();
+            return true;
+        };
+#define RV_TL(i) if (!tile(t0 + i, std::integral_constant<int, i>())) break;
+        for (unsigned t0 = 0;; t0 += 4) { RV_TL(0) RV_TL(1) RV_TL(2) RV_TL(3) }
+#undef RV_TL
+        accs[cur_vl * CC + c] = acc;
+        if (lane == 0) __hip_atomic_store(&prog[j], tagv | 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (R.trace && lane == 0) {
+            unsigned long long* tr = R.trace + ((size_t)frame * RES_MAXB + j) * 4;
+            tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = ((unsigned long long)n_own << 32) | n_t; tr[3] = t_spin;
+        }
+    }
+    __syncthreads();
+    // every vertex of the frame belongs to one block: all sums are written, empty lists as 0
+    const unsigned short* verts = R.blk_verts + ((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV;
+    for (unsigned e = threadIdx.x; e < n_own * CC; e += 512) values[((size_t)f0 + verts[e / CC]) * C + e % CC] = accs[e];
+}
+
+static unsigned g_resident_tag = 0;
+
+static int resident_ring() {
+    const int ring = std::getenv("RVSEG_SPLAT_RESIDENT_RING") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_RING")) : 8;
+    return ring == 16 ? 16 : 8;
+}
+
+int resident_block_capacity() {
+    static int cap[2] = {-1, -1};
+    const int which = resident_ring() == 16 ? 1 : 0;
+    if (cap[which] < 0) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t pr;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&pr, dev);
+        if (e == hipSuccess) {
+            if (which) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 16, 8>, 512, 0);
+            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4>, 512, 0);
+        }
+        cap[which] = e == hipSuccess ? per_cu * pr.multiProcessorCount : 0;
+    }
+    return cap[which];
+}
+
+static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
+    const unsigned NG = (unsigned)L.n_groups;
+    const unsigned rounds = ((unsigned)L.n_frames + NG - 1u) / NG;
+    g_resident_tag = (g_resident_tag % 0x7FFFu) + 1u;
+    const ValueView sv{const_cast<float*>(src), 0, 0};
+    if (resident_ring() == 8) splat_resident_kernel<9, 8, 4><<<dim3(rounds * (unsigned)R.B * NG), dim3(512), 0, s>>>(L, R, sv, values, g_resident_tag, slot);
+    else splat_resident_kernel<9, 16, 8><<<dim3(rounds * (unsigned)R.B * NG), dim3(512), 0, s>>>(L, R, sv, values, g_resident_tag, slot);
 }
 
 int csr_pix_per_block() { return CS_PIX; }

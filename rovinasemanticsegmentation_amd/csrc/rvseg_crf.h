@@ -65,6 +65,34 @@ struct SplatQueueDev {
     unsigned cap_groups;
 };
 
+// Band-interleaved resident schedule of the ordered splat ("resident bands").  A frame's
+// vertices are dealt to B blocks that all stay on the chip for the whole launch; a block walks ITS vertices band after
+// band of `band_wb` wave-blocks of points, so the d+1 readers of a point's row pass within a few bands of each other
+// and meet in the XCD's L2, while every chain stays inside one block (sums never travel between blocks: no hand-off,
+// no dependency -- the pacing is a hint, not a condition of correctness).  The walk is a list of tiles built once per
+// lattice.  A tile is one step of the block: seven slots, each up to 64 consecutive entries of one vertex.  Inside a
+// band the 64-entry chunks of the block's vertices are packed into the fewest tiles that keep a vertex's chunks in
+// different tiles, in order (wrap-around rule: tiles = max(longest vertex, chunks / 7)); which vertex a slot serves
+// changes from tile to tile, so the running sums live in LDS and a slot swaps its sum when its vertex changes.
+constexpr int RES_MAXB = 16;          // blocks per frame at most
+constexpr int RES_MAX_OWNV = 256;     // vertices a block can own (their running sums live in LDS)
+constexpr int RES_MAX_VERTS = 2048;   // vertices of a frame the planner handles
+constexpr int RES_MAX_BANDS = 512;
+struct SplatResidentDev {
+    unsigned* tdesc;             // [n_frames][7][cap_tiles]: (first entry - frame's first entry) << 7 | entries (0..64)
+    unsigned short* tvl;         // [n_frames][7][cap_tiles]: block-local vertex of the slot (n_own = nobody: entries is 0)
+    unsigned* tinfo;             // [n_frames][cap_tiles]: band << 16 | most entries of a slot
+    unsigned* blk_tile0;         // [n_frames][RES_MAXB + 1]: block j walks tiles [blk_tile0[j], blk_tile0[j + 1]) of its frame
+    unsigned short* blk_verts;   // [n_frames][RES_MAXB][RES_MAX_OWNV]: frame-local vertex of each block-local one
+    unsigned* blk_nown;          // [n_frames][RES_MAXB]
+    unsigned* jb_tile;           // [n_frames][RES_MAXB][n_bands + 1]: first tile of (block, band), relative to the frame
+    unsigned* prog;              // [2 scratch slots][n_frames][RES_MAXB]: launch tag << 16 | band reached
+    int* flags;                  // [0] frames the planner could not handle, [1] = 1: schedule valid
+    unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) {start, end, tiles, ticks spent waiting for the pace} (10 ns ticks)
+    int B, band_wb, n_bands, window;
+    unsigned cap_tiles;
+};
+
 // Where the lattice features come from.
 struct FeatureSource {
     int mode;            // 0: feat array P x d; 1: frame mode (cloud + colours, d = 6)
@@ -111,7 +139,11 @@ void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 // own_q: src is the mean-field loop's own Q * norm (finite, non-negative): enables the select-free producer
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q = false,
-                  const SplatQueueDev* queue = nullptr);
+                  const SplatQueueDev* queue = nullptr, const SplatResidentDev* resident = nullptr, int slot = 0);
+// builds the resident band schedule from the counting-sort table (after launch_lattice_finish)
+void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& r, hipStream_t s);
+// how many blocks of the resident splat kernel fit on the device at once (0: unknown)
+int resident_block_capacity();
 // builds the band-major queue from the counting-sort table (after launch_lattice_finish)
 void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s);
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks = false);

@@ -17,6 +17,9 @@ struct LatticeBufs {
     DevBuf q_items, q_cnt, q_off, q_small, q_vprog, q_trace;   // band-major splat queue (RVSEG_SPLAT_QUEUE=1)
     SplatQueueDev queue{};
     bool queue_on = false;
+    DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_trace;   // resident band schedule of the splat
+    SplatResidentDev resident{};
+    bool resident_on = false;
     LatticeDev dev{};
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
@@ -55,7 +58,8 @@ static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
                      &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist,
-                     &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace};
+                     &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace,
+                     &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_trace};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -207,6 +211,57 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         }
         b.queue_on = true;
     }
+    // Resident band schedule of the mean-field splat: chunks of many frames, whose splat is
+    // bound by the bytes the list-major walk re-reads.  All n_frames x B blocks have to be on the chip together.
+    b.resident_on = false;
+    {
+        const int res_env = std::getenv("RVSEG_SPLAT_RESIDENT") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT")) : 1;
+        const int b_env = std::getenv("RVSEG_SPLAT_RESIDENT_B") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_B")) : 0;
+        const int band_env = std::getenv("RVSEG_SPLAT_RESIDENT_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_BAND")) : 8;
+        const int win_env = std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW")) : -1;   // measured: pacing costs more than its locality saves (the kernel is issue bound)
+        const int min_frames = res_env > 1 ? 1 : 17;   // 2 = also for few frames (experiments)
+        const int capacity = resident_block_capacity();
+        int B = b_env > 0 ? b_env : (n_frames > 0 ? capacity / n_frames : 0);
+        B = B > RES_MAXB ? RES_MAXB : B;
+        if (B > 12 && b_env <= 0) B = 12;
+        if (res_env && !b.queue_on && L.bh && d == 6 && n_frames >= min_frames && B >= 2 && (long long)n_frames * B <= capacity &&
+            7ll * N < (1ll << 24)) {
+            SplatResidentDev& R = b.resident;
+            R.B = B;
+            R.band_wb = band_env < 1 ? 1 : (band_env > 32 ? 32 : band_env);
+            R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb;
+            while (R.n_bands > RES_MAX_BANDS) { R.band_wb *= 2; R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb; }
+            R.window = win_env;
+            R.cap_tiles = (unsigned)(N / 8 + 1024);
+            if (std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES")) {   // (tests shrink it to see the planner give up)
+                const int ct = std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES"));
+                if (ct > 0 && (unsigned)ct < R.cap_tiles) R.cap_tiles = (unsigned)ct;
+            }
+            {
+                const size_t small = (16 + (size_t)n_frames * (RES_MAXB + 1) + (size_t)n_frames * RES_MAXB + 2 * (size_t)n_frames * RES_MAXB) * 4;
+                if ((st = dev_reserve(ctx, b.r_desc, (size_t)n_frames * 7 * R.cap_tiles * 4)) != RVSEG_OK) return st;
+                if ((st = dev_reserve(ctx, b.r_vl, (size_t)n_frames * 7 * R.cap_tiles * 2)) != RVSEG_OK) return st;
+                if ((st = dev_reserve(ctx, b.r_info, (size_t)n_frames * R.cap_tiles * 4)) != RVSEG_OK) return st;
+                if ((st = dev_reserve(ctx, b.r_small, small)) != RVSEG_OK) return st;
+                if ((st = dev_reserve(ctx, b.r_verts, (size_t)n_frames * RES_MAXB * RES_MAX_OWNV * 2)) != RVSEG_OK) return st;
+                if ((st = dev_reserve(ctx, b.r_jb, (size_t)n_frames * RES_MAXB * (R.n_bands + 1) * 4)) != RVSEG_OK) return st;
+                R.tdesc = b.r_desc.as<unsigned>(); R.tvl = b.r_vl.as<unsigned short>(); R.tinfo = b.r_info.as<unsigned>();
+                unsigned* sm = b.r_small.as<unsigned>();
+                R.flags = reinterpret_cast<int*>(sm); sm += 16;
+                R.blk_tile0 = sm; sm += (size_t)n_frames * (RES_MAXB + 1);
+                R.blk_nown = sm; sm += (size_t)n_frames * RES_MAXB;
+                R.prog = sm;
+                R.blk_verts = b.r_verts.as<unsigned short>();
+                R.jb_tile = b.r_jb.as<unsigned>();
+                R.trace = nullptr;
+                if (std::getenv("RVSEG_SPLAT_RESIDENT_TRACE")) {
+                    if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 32)) != RVSEG_OK) return st;
+                    R.trace = b.r_trace.as<unsigned long long>();
+                }
+                b.resident_on = true;
+            }
+        }
+    }
     return RVSEG_OK;
 }
 
@@ -240,6 +295,11 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
         RV_HIP(ctx, hipMemsetAsync(b.q_vprog.p, 0xFF, (size_t)L.m_bound * 16 * 8, s));
         launch_queue_build(L, b.queue, s);
         tr("queue");
+    }
+    if (b.resident_on) {
+        RV_HIP(ctx, hipMemsetAsync(b.resident.prog, 0, 2 * (size_t)L.n_frames * RES_MAXB * 4, s));
+        launch_resident_plan(L, b.resident, s);
+        tr("resident plan");
     }
     rvseg_status st = values_reserve(ctx, cs, L.m_bound, 1);
     if (st != RVSEG_OK) return st;
@@ -329,7 +389,8 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             const LatticeBufs& b = cs->lat[0];
             const bool seq = C <= 2;
             mark("splat");
-            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused, (b.queue_on && slot == 0) ? &b.queue : nullptr);
+            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused, (b.queue_on && slot == 0) ? &b.queue : nullptr,
+                         b.resident_on ? &b.resident : nullptr, slot);
             mark("blur");
             float* blurred = launch_blur(b.dev, C, seq, false, b_va.as<float>(), b_vb.as<float>(), s);
             if (fused) {
@@ -714,6 +775,25 @@ rvseg_status rvseg_lattice_neighbours(rvseg_ctx* ctx, int32_t* n1_out, int32_t* 
     }
     if (vstart) RV_HIP(ctx, hipMemcpy(vstart, lb.dev.vstart, (size_t)M * 4, hipMemcpyDeviceToHost));
     if (vend) RV_HIP(ctx, hipMemcpy(vend, lb.dev.vend, (size_t)M * 4, hipMemcpyDeviceToHost));
+    return RVSEG_OK;
+}
+
+// debug (not in rvseg.h): per-block trace of the last resident splat of the frame path's lattice, and the tile ranges
+extern "C" rvseg_status rvseg_debug_resident(rvseg_ctx* ctx, void* trace_out, size_t trace_cap, unsigned* tile0_out, size_t tile0_cap, int meta[6]) {
+    if (!ctx || !ctx->impl) return RVSEG_ERR_INVALID_ARG;
+    Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
+    if (!im->crf || im->crf->lat.empty() || !im->crf->lat[0].resident_on) return RVSEG_ERR_INVALID_ARG;
+    LatticeBufs& b = im->crf->lat[0];
+    RV_HIP(ctx, hipDeviceSynchronize());
+    const int nf = b.dev.n_frames;
+    meta[0] = b.resident.B; meta[1] = b.resident.band_wb; meta[2] = b.resident.n_bands; meta[3] = nf; meta[4] = RES_MAXB;
+    int fl[2] = {0, 0};
+    RV_HIP(ctx, hipMemcpy(fl, b.resident.flags, 8, hipMemcpyDeviceToHost));
+    meta[5] = fl[1];
+    if (trace_out && b.resident.trace && trace_cap >= (size_t)nf * RES_MAXB * 32)
+        RV_HIP(ctx, hipMemcpy(trace_out, b.resident.trace, (size_t)nf * RES_MAXB * 32, hipMemcpyDeviceToHost));
+    if (tile0_out && tile0_cap >= (size_t)nf * (RES_MAXB + 1) * 4)
+        RV_HIP(ctx, hipMemcpy(tile0_out, b.resident.blk_tile0, (size_t)nf * (RES_MAXB + 1) * 4, hipMemcpyDeviceToHost));
     return RVSEG_OK;
 }
 
