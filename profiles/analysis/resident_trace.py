@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 L = ctx.L
 L.rvseg_debug_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
 MAXB = 16
-tr = np.zeros((n, MAXB, 4), np.uint64); t0s = np.zeros((n, MAXB + 1), np.uint32); meta = (C.c_int * 6)()
+tr = np.zeros((n, MAXB, 8), np.uint64); t0s = np.zeros((n, MAXB + 1), np.uint32); meta = (C.c_int * 6)()
 st = L.rvseg_debug_resident(ctx.h, tr.ctypes.data_as(C.c_void_p), tr.nbytes, t0s.ctypes.data_as(C.c_void_p), t0s.nbytes, meta)
 B = meta[0]
 print("status", st, "B", B, "band_wb", meta[1], "n_bands", meta[2], "frames", meta[3], "valid", meta[5])
@@ -43,4 +43,6 @@ print("frame end times us: min %.0f median %.0f max %.0f; slowest frames %s; by 
 run = (end - start) / 100.0
 print("all blocks: us/tile (without waits) mean %.3f; heavy blocks (j=0) %.3f; others %.3f" %
       (((run - spin / 100.0).sum() / tiles.sum()), ((run - spin / 100.0)[:, 0].sum() / tiles[:, 0].sum()), ((run - spin / 100.0)[:, 1:].sum() / tiles[:, 1:].sum())))
+clk = tr[:, :, 4].astype(np.float64)
+print("shader clock: %.0f MHz (s_memtime ticks per elapsed us)" % (clk.sum() / np.maximum(run, 1e-9).sum()))
 print("waiting for the pace: %.1f%% of block time" % (100.0 * spin.sum() / 100.0 / run.sum()))

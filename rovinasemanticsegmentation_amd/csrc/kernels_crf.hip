@@ -1239,29 +1239,41 @@ __device__ __forceinline__ void resident_piece(const LatticeDev& L, int band_wb,
     k1 = w1 < L.wbpf ? fb[(size_t)w1 * Mf] : L.vend[f0 + lv];
 }
 
-// One block per frame: 64-entry chunks of every vertex (summed over the bands), vertices dealt to the B blocks
-// (longest first, each to the block with the fewest chunks so far), tiles of every (block, band), tile numbers.
-__global__ void __launch_bounds__(256)
+// One block per frame: deals the frame's vertices to the B blocks and numbers the tiles.  A block's tile count is
+// sum over bands of max(chunks of its longest vertex there, all its chunks there / 7), so the heavy vertices are placed
+// one at a time, longest first, each into the block whose count ends up smallest -- evaluated exactly, band by band,
+// by the whole workgroup (`profiles/analysis`: 1 111 tiles for the fullest block of a bench frame, which is the chain
+// of its heaviest vertex, against 1 346 when the blocks are balanced by chunk totals).  The many short vertices
+// that follow go to the block with the fewest tiles so far, priced at chunks / 7.
+constexpr int RES_PLAN_THREADS = 1024;
+__global__ void __launch_bounds__(RES_PLAN_THREADS)
 resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
     __shared__ unsigned chv[RES_MAX_VERTS];
     __shared__ unsigned short own[RES_MAXB][RES_MAX_OWNV];
-    __shared__ unsigned nown[RES_MAXB];
-    __shared__ unsigned T[RES_MAXB][RES_MAX_BANDS];
+    __shared__ unsigned nown[RES_MAXB], nheavy[RES_MAXB];
+    __shared__ unsigned T[RES_MAXB][RES_MAX_BANDS];   // greedy: (sum of chunks) << 8 | longest; then tiles, then their scan
+    __shared__ unsigned char chb[4][RES_MAX_BANDS];   // chunks per band of the vertex being placed and the next ones
+    __shared__ unsigned part[RES_PLAN_THREADS / 64];
+    __shared__ unsigned short heavy_lv[512];
+    __shared__ unsigned cur[RES_MAXB];
     __shared__ unsigned blk0[RES_MAXB + 1];
-    __shared__ int bad;
+    __shared__ int bad, choice;
     if (L.counters[1]) return;
     const int frame = blockIdx.x;
     const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
     const int f0 = L.fstart[frame] < Mtot ? L.fstart[frame] : Mtot;
     const int f1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
     const int Mf = f1 - f0, nb = R.n_bands, B = R.B;
-    if (threadIdx.x == 0) bad = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) bad = 0;
+    if (tid < RES_MAXB) { nown[tid] = 0; nheavy[tid] = 0; cur[tid] = 0; }
+    for (int i = tid; i < B * nb; i += RES_PLAN_THREADS) T[i / nb][i % nb] = 0;
     __syncthreads();
     if (Mf > RES_MAX_VERTS) {
-        if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1);
+        if (tid == 0) atomicAdd(&R.flags[0], 1);
         return;
     }
-    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
+    for (int lv = tid; lv < Mf; lv += RES_PLAN_THREADS) {
         unsigned k0, k1, ch = 0;
         resident_piece(L, R.band_wb, f0, Mf, lv, 0, k0, k1);
         for (int b = 0; b < nb; b++) {
@@ -1272,24 +1284,89 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
         chv[lv] = ch;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned load[RES_MAXB];
-        for (int j = 0; j < B; j++) { load[j] = 0; nown[j] = 0; }
-        for (int k = 0; k < Mf; k++) {
+    // ---- the heavy vertices, exactly.  Wave w evaluates block w % B on the bands w / B, w / B + wpj, ... (64 at a time)
+    const int wpj = (RES_PLAN_THREADS / 64) / B;              // waves per block (B <= 16)
+    const int my_j = wave % B, my_part = wave / B;
+    // heavy = at least 12 chunks; `vorder` is sorted by length, so they are (about) a prefix of it: its length is counted
+    if (tid == 0) choice = 0;
+    __syncthreads();
+    if (tid < 512 && tid < Mf && chv[(int)L.vorder[f0 + tid] - f0] >= 12u) atomicAdd(&choice, 1);
+    __syncthreads();
+    const int n_heavy = choice;
+    __syncthreads();
+    // their chunks per band, once, in a table the placement loop streams through
+    unsigned char* hc = R.heavy_ch + (size_t)frame * 512 * nb;
+    for (int i = tid; i < n_heavy * nb; i += RES_PLAN_THREADS) {
+        const int k = i / nb, b = i - k * nb;
+        unsigned k0, k1;
+        resident_piece(L, R.band_wb, f0, Mf, (int)L.vorder[f0 + k] - f0, b, k0, k1);
+        hc[i] = (unsigned char)((k1 - k0 + 63u) >> 6);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < n_heavy; k += RES_PLAN_THREADS) heavy_lv[k] = (unsigned short)((int)L.vorder[f0 + k] - f0);
+    // the table rows travel ahead of the vertex being placed: a row is loaded (threads b < nb) one iteration before it
+    // is stored into the ring of four, two before it is used
+    if (tid < nb) { chb[0][tid] = n_heavy ? hc[tid] : 0; chb[1][tid] = 1 < n_heavy ? hc[(size_t)nb + tid] : 0; }
+    unsigned rpend = (tid < nb && 2 < n_heavy) ? hc[(size_t)2 * nb + tid] : 0u;
+    __syncthreads();
+    for (int k = 0; k < n_heavy; k++) {
+        const unsigned char* cb = chb[k & 3];
+        if (tid < nb) chb[(k + 2) & 3][tid] = (unsigned char)rpend;
+        rpend = (tid < nb && k + 3 < n_heavy) ? hc[(size_t)(k + 3) * nb + tid] : 0u;
+        unsigned sum = 0;
+        if (my_part < wpj)
+            for (int b = my_part * 64 + lane; b < nb; b += wpj * 64) {
+                const unsigned pk = T[my_j][b], c = cb[b];
+                const unsigned mx = (pk & 255u) > c ? (pk & 255u) : c, t7 = ((pk >> 8) + c + 6u) / 7u;
+                sum += mx > t7 ? mx : t7;
+            }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) part[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            int best = -1; unsigned best_t = 0, best_inc = 0;
+            for (int j = 0; j < B; j++) {
+                if (nown[j] >= (unsigned)RES_MAX_OWNV) continue;
+                unsigned t = 0;
+                for (int q = 0; q < wpj; q++) t += part[j + q * B];
+                const unsigned inc = t - cur[j];
+                if (best < 0 || t < best_t || (t == best_t && inc < best_inc)) { best = j; best_t = t; best_inc = inc; }
+            }
+            choice = best;
+            if (best < 0) bad = 1;
+            else { cur[best] = best_t; own[best][nown[best]++] = heavy_lv[k]; }
+        }
+        __syncthreads();
+        if (bad) break;
+        const int jc = choice;
+        if (tid < nb) {
+            const unsigned pk = T[jc][tid], c = cb[tid];
+            T[jc][tid] = (((pk >> 8) + c) << 8) | ((pk & 255u) > c ? (pk & 255u) : c);
+        }
+        __syncthreads();
+    }
+    if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
+    // ---- the rest: fewest tiles so far, a vertex priced at chunks / 7 (sevenths of a tile in `cur7`)
+    if (tid == 0) {
+        unsigned cur7[RES_MAXB];
+        for (int j = 0; j < B; j++) { cur7[j] = cur[j] * 7u; nheavy[j] = nown[j]; }
+        for (int k = n_heavy; k < Mf; k++) {
             const int lv = (int)L.vorder[f0 + k] - f0;
             int best = -1;
-            for (int j = 0; j < B; j++) if (nown[j] < (unsigned)RES_MAX_OWNV && (best < 0 || load[j] < load[best])) best = j;
+            for (int j = 0; j < B; j++) if (nown[j] < (unsigned)RES_MAX_OWNV && (best < 0 || cur7[j] < cur7[best])) best = j;
             if (best < 0 || lv < 0 || lv >= Mf) { bad = 1; break; }
-            load[best] += chv[lv] + 1u;
+            cur7[best] += chv[lv] + 1u;
             own[best][nown[best]++] = (unsigned short)lv;
         }
     }
     __syncthreads();
-    if (bad) { if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1); return; }
-    for (int idx = threadIdx.x; idx < B * nb; idx += 256) {
+    if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
+    for (int idx = tid; idx < B * nb; idx += RES_PLAN_THREADS) {
         const int j = idx / nb, b = idx - j * nb;
-        unsigned sum = 0, mx = 0;
-        for (unsigned u = 0; u < nown[j]; u++) {
+        const unsigned pk = T[j][b];
+        unsigned sum = pk >> 8, mx = pk & 255u;
+        for (unsigned u = nheavy[j]; u < nown[j]; u++) {
             unsigned k0, k1;
             resident_piece(L, R.band_wb, f0, Mf, own[j][u], b, k0, k1);
             const unsigned ch = (k1 - k0 + 63u) >> 6;
@@ -1300,27 +1377,27 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
         T[j][b] = t > mx ? t : mx;
     }
     __syncthreads();
-    if ((int)threadIdx.x < B) {
+    if (tid < B) {
         unsigned run = 0;
-        for (int b = 0; b < nb; b++) { const unsigned t = T[threadIdx.x][b]; T[threadIdx.x][b] = run; run += t; }
-        blk0[threadIdx.x + 1] = run;
+        for (int b = 0; b < nb; b++) { const unsigned t = T[tid][b]; T[tid][b] = run; run += t; }
+        blk0[tid + 1] = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         blk0[0] = 0;
         for (int j = 0; j < B; j++) blk0[j + 1] += blk0[j];
         if (blk0[B] > R.cap_tiles) bad = 1;
     }
     __syncthreads();
-    if (bad) { if (threadIdx.x == 0) atomicAdd(&R.flags[0], 1); return; }
+    if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
     unsigned* jb = R.jb_tile + (size_t)frame * RES_MAXB * (nb + 1);
-    for (int idx = threadIdx.x; idx < B * (nb + 1); idx += 256) {
+    for (int idx = tid; idx < B * (nb + 1); idx += RES_PLAN_THREADS) {
         const int j = idx / (nb + 1), b = idx - j * (nb + 1);
         jb[idx] = b < nb ? blk0[j] + T[j][b] : blk0[j + 1];
     }
-    for (int j = threadIdx.x; j <= B; j += 256) R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j] = blk0[j];
-    for (int j = threadIdx.x; j < B; j += 256) R.blk_nown[(size_t)frame * RES_MAXB + j] = nown[j];
-    for (int idx = threadIdx.x; idx < B * RES_MAX_OWNV; idx += 256) {
+    for (int j = tid; j <= B; j += RES_PLAN_THREADS) R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j] = blk0[j];
+    for (int j = tid; j < B; j += RES_PLAN_THREADS) R.blk_nown[(size_t)frame * RES_MAXB + j] = nown[j];
+    for (int idx = tid; idx < B * RES_MAX_OWNV; idx += RES_PLAN_THREADS) {
         const int j = idx / RES_MAX_OWNV, u = idx - j * RES_MAX_OWNV;
         R.blk_verts[((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV + u] = (unsigned)u < nown[j] ? own[j][u] : (unsigned short)0;
     }
@@ -1384,7 +1461,7 @@ resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
 
 void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStream_t s) {
     (void)hipMemsetAsync(R.flags, 0, 2 * sizeof(int), s);
-    resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(256), 0, s>>>(L, R);
+    resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(RES_PLAN_THREADS), 0, s>>>(L, R);
     resident_seal_kernel<<<dim3(1), dim3(1), 0, s>>>(L, R);
     resident_fill_kernel<<<dim3((unsigned)((R.B * R.n_bands + 63) / 64), (unsigned)L.n_frames), dim3(64), 0, s>>>(L, R);
 }
@@ -1407,6 +1484,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
     static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
     __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
+    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile {info, vertex of slot 0 .. 6}
     if (L.counters[1] || !R.flags[1]) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1423,6 +1501,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
     for (unsigned e = threadIdx.x; e < (n_own + 1u) * CC; e += 512) accs[e] = 0.0f;
     unsigned* prog = R.prog + ((size_t)slot * L.n_frames + frame) * RES_MAXB;
     const unsigned long long t_start = R.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long c_start = R.trace ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_spin = 0;
     if (wave == G) __builtin_amdgcn_s_setprio(3);
     else if (n_t > 256u) __builtin_amdgcn_s_setprio(1);
@@ -1487,84 +1566,107 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         const int gi = live ? lane / CC : 0;
         const int c = live ? lane % CC : 0;
         const unsigned* I = R.tinfo + (size_t)frame * R.cap_tiles + tb;
-        const unsigned short* V = R.tvl + ((size_t)frame * 7 + gi) * R.cap_tiles + tb;
-        auto load_info = [&](unsigned first) -> unsigned {
+        const unsigned short* V = R.tvl + (size_t)frame * 7 * R.cap_tiles + tb;
+        // What a tile needs besides its products -- height and band (uniform) and the vertex of the lane's slot -- comes
+        // from an LDS table of 2 x 64 tiles x 8 words {info, vertex of slot 0 .. 6}.  The adder refills it 64 tiles at a
+        // time: lane = tile, eight global loads that stay in flight for 64 tiles and are stored when their half of the
+        // table comes up.  Per tile that leaves two LDS reads, issued a tile ahead: the loop's critical path is the 64
+        // dependent adds and the barrier, nothing else may wait on it (no load per tile, no register shuffling).
+        unsigned pend[8];
+        auto batch_load = [&](unsigned first) {
             const unsigned t = first + (unsigned)lane;
-            return n_t ? I[t < n_t ? t : n_t - 1u] : 0u;
+            const unsigned tc = n_t ? (t < n_t ? t : n_t - 1u) : 0u;
+            pend[0] = n_t ? I[tc] : 0u;
+#pragma unroll
+            for (int i = 0; i < G; i++) pend[1 + i] = n_t ? (unsigned)V[(size_t)i * R.cap_tiles + tc] : n_own;
         };
-        auto load_vl = [&](unsigned t) -> unsigned { return (live && t < n_t) ? (unsigned)V[t] : n_own; };
+        auto batch_store = [&](unsigned first) {
+            const bool in = first + (unsigned)lane < n_t;
+            unsigned* row = &ainfo[(first >> 6) & 1u][lane][0];
+            row[0] = pend[0];
+#pragma unroll
+            for (int i = 0; i < G; i++) row[1 + i] = in ? pend[1 + i] : n_own;
+        };
         auto poll = [&]() -> unsigned { return __hip_atomic_load(&prog[(unsigned)lane < B ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         const unsigned tagv = tag << 16;
         if (lane == 0) __hip_atomic_store(&prog[j], n_t ? tagv : (tagv | 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned icur = 0u, inxt = load_info(0u);
-        unsigned polled = poll();
-        unsigned vl[4] = {load_vl(0u), load_vl(1u), load_vl(2u), load_vl(3u)};   // the slot's vertex, four tiles ahead
+        batch_load(0u);
+        batch_store(0u);
+        batch_load(64u);
+        unsigned polled = R.window >= 0 ? poll() : 0u;
         unsigned cur_vl = n_own, cur_band = 0u;
         bool pacing = R.window >= 0;
         float acc = 0.0f;
-        __syncthreads();
-        auto tile = [&](unsigned t, auto S) -> bool {
-            constexpr int s = decltype(S)::value;
-            if (t >= n_t) return false;
-            if ((t & 63u) == 0u) { icur = inxt; inxt = load_info(t + 64u); }
-            const unsigned info = __builtin_amdgcn_readlane(icur, (int)(t & 63u));
-            const unsigned nmax = info & 255u, band = info >> 16;
-            const unsigned v = vl[s];
-            vl[s] = load_vl(t + 4u);
-            if (v != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v * CC + c]; cur_vl = v; }
-            if (band != cur_band) {
-                cur_band = band;
-                if (lane == 0) __hip_atomic_store(&prog[j], tagv | band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pacing) {
-                    auto behind = [&](unsigned pv) -> bool {
-                        // a word of another launch: that block has not started yet
-                        return (unsigned)lane < B && ((pv >> 16) != tag || (pv & 0xFFFFu) + (unsigned)R.window < band);
-                    };
-                    if (__ballot(behind(polled))) {
-                        const unsigned long long ts = R.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                        unsigned spins = 0;
-                        for (;;) {
-                            polled = poll();
-                            if (!__ballot(behind(polled))) break;
-                            if (++spins > 256u) { pacing = false; break; }   // some block is not running: stop waiting for good
-                            __builtin_amdgcn_s_sleep(8);
-                        }
-                        if (R.trace) t_spin += __builtin_amdgcn_s_memrealtime() - ts;
-                    }
-                    polled = poll();   // consumed at the next band
+        unsigned v_n = n_own, info_n = 0u;
+        // issues the two table reads of tile t (results in v_n / info_n: used after the next barrier)
+        auto prep = [&](unsigned t) {
+            if (t >= n_t) return;
+            if ((t & 63u) == 0u && t) { batch_store(t); batch_load(t + 64u); }
+            const unsigned* row = &ainfo[(t >> 6) & 1u][t & 63u][0];
+            info_n = row[0];
+            v_n = live ? row[1 + gi] : n_own;
+        };
+        auto pace = [&](unsigned band) {
+            cur_band = band;
+            if (lane == 0) __hip_atomic_store(&prog[j], tagv | band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!pacing) return;
+            auto behind = [&](unsigned pv) -> bool {
+                // a word of another launch: that block has not started yet
+                return (unsigned)lane < B && ((pv >> 16) != tag || (pv & 0xFFFFu) + (unsigned)R.window < band);
+            };
+            if (__ballot(behind(polled))) {
+                const unsigned long long ts = R.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                unsigned spins = 0;
+                for (;;) {
+                    polled = poll();
+                    if (!__ballot(behind(polled))) break;
+                    if (++spins > 256u) { pacing = false; break; }   // some block is not running: stop waiting for good
+                    __builtin_amdgcn_s_sleep(8);
                 }
+                if (R.trace) t_spin += __builtin_amdgcn_s_memrealtime() - ts;
             }
+            polled = poll();   // consumed at the next band
+        };
+        prep(0u);
+        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(info_n) >> 16; if (b0 != cur_band) pace(b0); }
+        __syncthreads();
+        for (unsigned t = 0; t < n_t; t++) {
+            const unsigned nmax = __builtin_amdgcn_readfirstlane(info_n) & 255u;
+            // the slot's vertex changed: park the sum, fetch the other one.  Store before load, one wave: a chain that
+            // moved here from another slot of the previous tile is handed over in order.
+            if (v_n != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v_n * CC + c]; cur_vl = v_n; }
             const float* pr = prod[t & 1u][gi][c];
             if (nmax > 32u) {
                 float4 q[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+                prep(t + 1u);
 #pragma unroll
                 for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             } else if (nmax > 16u) {
                 float4 q[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+                prep(t + 1u);
 #pragma unroll
                 for (int i = 0; i < 8; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             } else {
                 float4 q[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+                prep(t + 1u);
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             }
+            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(info_n) >> 16; if (bn != cur_band) pace(bn); }
             __syncthreads();
-            return true;
-        };
-#define RV_TL(i) if (!tile(t0 + i, std::integral_constant<int, i>())) break;
-        for (unsigned t0 = 0;; t0 += 4) { RV_TL(0) RV_TL(1) RV_TL(2) RV_TL(3) }
-#undef RV_TL
+        }
         accs[cur_vl * CC + c] = acc;
         if (lane == 0) __hip_atomic_store(&prog[j], tagv | 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (R.trace && lane == 0) {
-            unsigned long long* tr = R.trace + ((size_t)frame * RES_MAXB + j) * 4;
+            unsigned long long* tr = R.trace + ((size_t)frame * RES_MAXB + j) * 8;
             tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime(); tr[2] = ((unsigned long long)n_own << 32) | n_t; tr[3] = t_spin;
+            tr[4] = __builtin_amdgcn_s_memtime() - c_start;   // shader clocks
         }
     }
     __syncthreads();
@@ -1580,6 +1682,9 @@ static int resident_ring() {
     return ring == 16 ? 16 : 8;
 }
 
+static int g_resident_cus = 0;
+int resident_cu_count() { (void)resident_block_capacity(); return g_resident_cus; }
+
 int resident_block_capacity() {
     static int cap[2] = {-1, -1};
     const int which = resident_ring() == 16 ? 1 : 0;
@@ -1593,6 +1698,7 @@ int resident_block_capacity() {
             else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4>, 512, 0);
         }
         cap[which] = e == hipSuccess ? per_cu * pr.multiProcessorCount : 0;
+        if (e == hipSuccess) g_resident_cus = pr.multiProcessorCount;
     }
     return cap[which];
 }

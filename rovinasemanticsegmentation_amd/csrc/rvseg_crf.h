@@ -86,9 +86,10 @@ struct SplatResidentDev {
     unsigned short* blk_verts;   // [n_frames][RES_MAXB][RES_MAX_OWNV]: frame-local vertex of each block-local one
     unsigned* blk_nown;          // [n_frames][RES_MAXB]
     unsigned* jb_tile;           // [n_frames][RES_MAXB][n_bands + 1]: first tile of (block, band), relative to the frame
+    unsigned char* heavy_ch;     // plan scratch [n_frames][512][n_bands]: chunks per band of the frame's heaviest vertices
     unsigned* prog;              // [2 scratch slots][n_frames][RES_MAXB]: launch tag << 16 | band reached
     int* flags;                  // [0] frames the planner could not handle, [1] = 1: schedule valid
-    unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) {start, end, tiles, ticks spent waiting for the pace} (10 ns ticks)
+    unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) 8 words: start, end, tiles, ticks spent waiting for the pace (10 ns ticks), shader clocks
     int B, band_wb, n_bands, window;
     unsigned cap_tiles;
 };
@@ -144,6 +145,7 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
 void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& r, hipStream_t s);
 // how many blocks of the resident splat kernel fit on the device at once (0: unknown)
 int resident_block_capacity();
+int resident_cu_count();
 // builds the band-major queue from the counting-sort table (after launch_lattice_finish)
 void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s);
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks = false);

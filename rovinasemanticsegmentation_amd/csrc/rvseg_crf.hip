@@ -17,7 +17,7 @@ struct LatticeBufs {
     DevBuf q_items, q_cnt, q_off, q_small, q_vprog, q_trace;   // band-major splat queue (RVSEG_SPLAT_QUEUE=1)
     SplatQueueDev queue{};
     bool queue_on = false;
-    DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_trace;   // resident band schedule of the splat
+    DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_heavy, r_trace;   // resident band schedule of the splat
     SplatResidentDev resident{};
     bool resident_on = false;
     LatticeDev dev{};
@@ -59,7 +59,7 @@ static void lattice_free(LatticeBufs& b) {
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
                      &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist,
                      &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace,
-                     &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_trace};
+                     &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_heavy, &b.r_trace};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -221,11 +221,13 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         const int win_env = std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW")) : -1;   // measured: pacing costs more than its locality saves (the kernel is issue bound)
         const int min_frames = res_env > 1 ? 1 : 17;   // 2 = also for few frames (experiments)
         const int capacity = resident_block_capacity();
-        int B = b_env > 0 ? b_env : (n_frames > 0 ? capacity / n_frames : 0);
+        // one block per CU measured best (the tile loop is bound by its own barrier-coupled latencies, a second block on
+        // the CU slows both): B = CUs / frames, at least 2, at most 12
+        int B = b_env > 0 ? b_env : (n_frames > 0 ? resident_cu_count() / n_frames : 0);
+        if (b_env <= 0) B = B < 2 ? 2 : (B > 12 ? 12 : B);
         B = B > RES_MAXB ? RES_MAXB : B;
-        if (B > 12 && b_env <= 0) B = 12;
         if (res_env && !b.queue_on && L.bh && d == 6 && n_frames >= min_frames && B >= 2 && (long long)n_frames * B <= capacity &&
-            7ll * N < (1ll << 24)) {
+            7ll * N < (1ll << 24) && (long long)L.wbpf <= 32ll * RES_MAX_BANDS) {   // (bands stay under 64 wave-blocks: chunk counts fit 8 bits)
             SplatResidentDev& R = b.resident;
             R.B = B;
             R.band_wb = band_env < 1 ? 1 : (band_env > 32 ? 32 : band_env);
@@ -253,9 +255,11 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
                 R.prog = sm;
                 R.blk_verts = b.r_verts.as<unsigned short>();
                 R.jb_tile = b.r_jb.as<unsigned>();
+                if ((st = dev_reserve(ctx, b.r_heavy, (size_t)n_frames * 512 * R.n_bands)) != RVSEG_OK) return st;
+                R.heavy_ch = b.r_heavy.as<unsigned char>();
                 R.trace = nullptr;
                 if (std::getenv("RVSEG_SPLAT_RESIDENT_TRACE")) {
-                    if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 32)) != RVSEG_OK) return st;
+                    if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 64)) != RVSEG_OK) return st;
                     R.trace = b.r_trace.as<unsigned long long>();
                 }
                 b.resident_on = true;
@@ -790,8 +794,8 @@ extern "C" rvseg_status rvseg_debug_resident(rvseg_ctx* ctx, void* trace_out, si
     int fl[2] = {0, 0};
     RV_HIP(ctx, hipMemcpy(fl, b.resident.flags, 8, hipMemcpyDeviceToHost));
     meta[5] = fl[1];
-    if (trace_out && b.resident.trace && trace_cap >= (size_t)nf * RES_MAXB * 32)
-        RV_HIP(ctx, hipMemcpy(trace_out, b.resident.trace, (size_t)nf * RES_MAXB * 32, hipMemcpyDeviceToHost));
+    if (trace_out && b.resident.trace && trace_cap >= (size_t)nf * RES_MAXB * 64)
+        RV_HIP(ctx, hipMemcpy(trace_out, b.resident.trace, (size_t)nf * RES_MAXB * 64, hipMemcpyDeviceToHost));
     if (tile0_out && tile0_cap >= (size_t)nf * (RES_MAXB + 1) * 4)
         RV_HIP(ctx, hipMemcpy(tile0_out, b.resident.blk_tile0, (size_t)nf * (RES_MAXB + 1) * 4, hipMemcpyDeviceToHost));
     return RVSEG_OK;
