@@ -46,3 +46,4 @@ print("all blocks: us/tile (without waits) mean %.3f; heavy blocks (j=0) %.3f; o
 clk = tr[:, :, 4].astype(np.float64)
 print("shader clock: %.0f MHz (s_memtime ticks per elapsed us)" % (clk.sum() / np.maximum(run, 1e-9).sum()))
 print("waiting for the pace: %.1f%% of block time" % (100.0 * spin.sum() / 100.0 / run.sum()))
+

@@ -1246,15 +1246,16 @@ __device__ __forceinline__ void resident_piece(const LatticeDev& L, int band_wb,
 // of its heaviest vertex, against 1 346 when the blocks are balanced by chunk totals).  The many short vertices
 // that follow go to the block with the fewest tiles so far, priced at chunks / 7.
 constexpr int RES_PLAN_THREADS = 1024;
+constexpr int RES_HEAVY_MAX = 160;   // vertices placed exactly at most (numpy on a bench frame: 96 reach the result of 200; other frames need more)
+// dynamic LDS: T[B][nb] words, then the heavy table [heavy_cap][nb] bytes
 __global__ void __launch_bounds__(RES_PLAN_THREADS)
-resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
+resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned plan_lds[];
     __shared__ unsigned chv[RES_MAX_VERTS];
     __shared__ unsigned short own[RES_MAXB][RES_MAX_OWNV];
     __shared__ unsigned nown[RES_MAXB], nheavy[RES_MAXB];
-    __shared__ unsigned T[RES_MAXB][RES_MAX_BANDS];   // greedy: (sum of chunks) << 8 | longest; then tiles, then their scan
-    __shared__ unsigned char chb[4][RES_MAX_BANDS];   // chunks per band of the vertex being placed and the next ones
     __shared__ unsigned part[RES_PLAN_THREADS / 64];
-    __shared__ unsigned short heavy_lv[512];
+    __shared__ unsigned short lvo[RES_MAX_VERTS];   // the frame's vertices, longest list first (`vorder`, frame-local)
     __shared__ unsigned cur[RES_MAXB];
     __shared__ unsigned blk0[RES_MAXB + 1];
     __shared__ int bad, choice;
@@ -1265,59 +1266,52 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
     const int f1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
     const int Mf = f1 - f0, nb = R.n_bands, B = R.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) bad = 0;
+    unsigned* T = plan_lds;                                               // [B][nb]: greedy: (sum of chunks) << 8 | longest; then tiles, then their scan
+    unsigned char* hc = reinterpret_cast<unsigned char*>(plan_lds + B * nb);   // [heavy_cap][nb]
+    if (tid == 0) { bad = 0; choice = 0; }
     if (tid < RES_MAXB) { nown[tid] = 0; nheavy[tid] = 0; cur[tid] = 0; }
-    for (int i = tid; i < B * nb; i += RES_PLAN_THREADS) T[i / nb][i % nb] = 0;
+    for (int i = tid; i < B * nb; i += RES_PLAN_THREADS) T[i] = 0;
+    for (int lv = tid; lv < RES_MAX_VERTS; lv += RES_PLAN_THREADS) chv[lv] = 0;
     __syncthreads();
     if (Mf > RES_MAX_VERTS) {
         if (tid == 0) atomicAdd(&R.flags[0], 1);
         return;
     }
-    for (int lv = tid; lv < Mf; lv += RES_PLAN_THREADS) {
-        unsigned k0, k1, ch = 0;
-        resident_piece(L, R.band_wb, f0, Mf, lv, 0, k0, k1);
-        for (int b = 0; b < nb; b++) {
-            ch += (k1 - k0 + 63u) >> 6;
-            k0 = k1;
-            if (b + 1 < nb) { unsigned a; resident_piece(L, R.band_wb, f0, Mf, lv, b + 1, a, k1); }
-        }
-        chv[lv] = ch;
+    for (int k = tid; k < Mf; k += RES_PLAN_THREADS) {
+        const int lv = (int)L.vorder[f0 + k] - f0;
+        lvo[k] = (unsigned short)(lv < 0 ? 0 : (lv >= Mf ? Mf - 1 : lv));
+    }
+    // 64-entry chunks of every vertex, summed over the bands: one (vertex, band) piece per thread and step
+    for (int i = tid; i < Mf * nb; i += RES_PLAN_THREADS) {
+        const int b = i / Mf, lv = i - b * Mf;   // consecutive threads: consecutive vertices of one band (the table's row)
+        unsigned k0, k1;
+        resident_piece(L, R.band_wb, f0, Mf, lv, b, k0, k1);
+        const unsigned ch = (k1 - k0 + 63u) >> 6;
+        if (ch) atomicAdd(&chv[lv], ch);
     }
     __syncthreads();
     // ---- the heavy vertices, exactly.  Wave w evaluates block w % B on the bands w / B, w / B + wpj, ... (64 at a time)
     const int wpj = (RES_PLAN_THREADS / 64) / B;              // waves per block (B <= 16)
     const int my_j = wave % B, my_part = wave / B;
     // heavy = at least 12 chunks; `vorder` is sorted by length, so they are (about) a prefix of it: its length is counted
-    if (tid == 0) choice = 0;
-    __syncthreads();
-    if (tid < 512 && tid < Mf && chv[(int)L.vorder[f0 + tid] - f0] >= 12u) atomicAdd(&choice, 1);
+    if (tid < heavy_cap && tid < Mf && chv[lvo[tid]] >= 12u) atomicAdd(&choice, 1);
     __syncthreads();
     const int n_heavy = choice;
     __syncthreads();
-    // their chunks per band, once, in a table the placement loop streams through
-    unsigned char* hc = R.heavy_ch + (size_t)frame * 512 * nb;
+    // their chunks per band, once, in LDS: the placement loop below touches no global memory
     for (int i = tid; i < n_heavy * nb; i += RES_PLAN_THREADS) {
         const int k = i / nb, b = i - k * nb;
         unsigned k0, k1;
-        resident_piece(L, R.band_wb, f0, Mf, (int)L.vorder[f0 + k] - f0, b, k0, k1);
+        resident_piece(L, R.band_wb, f0, Mf, lvo[k], b, k0, k1);
         hc[i] = (unsigned char)((k1 - k0 + 63u) >> 6);
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int k = tid; k < n_heavy; k += RES_PLAN_THREADS) heavy_lv[k] = (unsigned short)((int)L.vorder[f0 + k] - f0);
-    // the table rows travel ahead of the vertex being placed: a row is loaded (threads b < nb) one iteration before it
-    // is stored into the ring of four, two before it is used
-    if (tid < nb) { chb[0][tid] = n_heavy ? hc[tid] : 0; chb[1][tid] = 1 < n_heavy ? hc[(size_t)nb + tid] : 0; }
-    unsigned rpend = (tid < nb && 2 < n_heavy) ? hc[(size_t)2 * nb + tid] : 0u;
     __syncthreads();
     for (int k = 0; k < n_heavy; k++) {
-        const unsigned char* cb = chb[k & 3];
-        if (tid < nb) chb[(k + 2) & 3][tid] = (unsigned char)rpend;
-        rpend = (tid < nb && k + 3 < n_heavy) ? hc[(size_t)(k + 3) * nb + tid] : 0u;
+        const unsigned char* cb = hc + (size_t)k * nb;
         unsigned sum = 0;
         if (my_part < wpj)
             for (int b = my_part * 64 + lane; b < nb; b += wpj * 64) {
-                const unsigned pk = T[my_j][b], c = cb[b];
+                const unsigned pk = T[my_j * nb + b], c = cb[b];
                 const unsigned mx = (pk & 255u) > c ? (pk & 255u) : c, t7 = ((pk >> 8) + c + 6u) / 7u;
                 sum += mx > t7 ? mx : t7;
             }
@@ -1335,14 +1329,14 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
             }
             choice = best;
             if (best < 0) bad = 1;
-            else { cur[best] = best_t; own[best][nown[best]++] = heavy_lv[k]; }
+            else { cur[best] = best_t; own[best][nown[best]++] = lvo[k]; }
         }
         __syncthreads();
         if (bad) break;
         const int jc = choice;
-        if (tid < nb) {
-            const unsigned pk = T[jc][tid], c = cb[tid];
-            T[jc][tid] = (((pk >> 8) + c) << 8) | ((pk & 255u) > c ? (pk & 255u) : c);
+        for (int b = tid; b < nb; b += RES_PLAN_THREADS) {
+            const unsigned pk = T[jc * nb + b], c = cb[b];
+            T[jc * nb + b] = (((pk >> 8) + c) << 8) | ((pk & 255u) > c ? (pk & 255u) : c);
         }
         __syncthreads();
     }
@@ -1352,7 +1346,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
         unsigned cur7[RES_MAXB];
         for (int j = 0; j < B; j++) { cur7[j] = cur[j] * 7u; nheavy[j] = nown[j]; }
         for (int k = n_heavy; k < Mf; k++) {
-            const int lv = (int)L.vorder[f0 + k] - f0;
+            const int lv = lvo[k];
             int best = -1;
             for (int j = 0; j < B; j++) if (nown[j] < (unsigned)RES_MAX_OWNV && (best < 0 || cur7[j] < cur7[best])) best = j;
             if (best < 0 || lv < 0 || lv >= Mf) { bad = 1; break; }
@@ -1362,24 +1356,29 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
     }
     __syncthreads();
     if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
-    for (int idx = tid; idx < B * nb; idx += RES_PLAN_THREADS) {
+    // tiles of every (block, band): the light vertices' chunks join the packed sums, a wave per (block, band)
+    for (int idx = wave; idx < B * nb; idx += RES_PLAN_THREADS / 64) {
         const int j = idx / nb, b = idx - j * nb;
-        const unsigned pk = T[j][b];
-        unsigned sum = pk >> 8, mx = pk & 255u;
-        for (unsigned u = nheavy[j]; u < nown[j]; u++) {
+        unsigned sum = 0, mx = 0;
+        for (unsigned u = nheavy[j] + lane; u < nown[j]; u += 64) {
             unsigned k0, k1;
             resident_piece(L, R.band_wb, f0, Mf, own[j][u], b, k0, k1);
             const unsigned ch = (k1 - k0 + 63u) >> 6;
             sum += ch;
             mx = ch > mx ? ch : mx;
         }
-        const unsigned t = (sum + 6u) / 7u;
-        T[j][b] = t > mx ? t : mx;
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); const unsigned m2 = __shfl_xor(mx, o, 64); mx = m2 > mx ? m2 : mx; }
+        if (lane == 0) {
+            const unsigned pk = T[idx];
+            sum += pk >> 8; mx = (pk & 255u) > mx ? (pk & 255u) : mx;
+            const unsigned t = (sum + 6u) / 7u;
+            T[idx] = t > mx ? t : mx;
+        }
     }
     __syncthreads();
     if (tid < B) {
         unsigned run = 0;
-        for (int b = 0; b < nb; b++) { const unsigned t = T[tid][b]; T[tid][b] = run; run += t; }
+        for (int b = 0; b < nb; b++) { const unsigned t = T[tid * nb + b]; T[tid * nb + b] = run; run += t; }
         blk0[tid + 1] = run;
     }
     __syncthreads();
@@ -1393,7 +1392,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R) {
     unsigned* jb = R.jb_tile + (size_t)frame * RES_MAXB * (nb + 1);
     for (int idx = tid; idx < B * (nb + 1); idx += RES_PLAN_THREADS) {
         const int j = idx / (nb + 1), b = idx - j * (nb + 1);
-        jb[idx] = b < nb ? blk0[j] + T[j][b] : blk0[j + 1];
+        jb[idx] = b < nb ? blk0[j] + T[j * nb + b] : blk0[j + 1];
     }
     for (int j = tid; j <= B; j += RES_PLAN_THREADS) R.blk_tile0[(size_t)frame * (RES_MAXB + 1) + j] = blk0[j];
     for (int j = tid; j < B; j += RES_PLAN_THREADS) R.blk_nown[(size_t)frame * RES_MAXB + j] = nown[j];
@@ -1407,16 +1406,20 @@ __global__ void resident_seal_kernel(LatticeDev L, SplatResidentDev R) {
     R.flags[1] = (R.flags[0] == 0 && L.counters[1] == 0) ? 1 : 0;
 }
 
-// One thread per (block, band): packs the chunks of the block's vertices into the band's T tiles x 7 slots by the
-// wrap-around rule -- the cells are filled slot after slot, a vertex that does not fit the rest of a slot continues at
-// the top of the next one; because a vertex has at most T chunks the two parts never share a tile, and its chunks
-// are numbered by tile, so they are summed in list order whatever slot they sit in.
-__global__ void __launch_bounds__(64)
+// One wave per (block, band): packs the chunks of the block's vertices into the band's T tiles x 7 slots by the
+// wrap-around rule.  The cells are numbered slot after slot; a vertex takes the next `chunks` cells (a prefix sum over
+// the block's vertices, kept in LDS), and when its cells run over the end of a slot it continues at the top of the next
+// one.  Because a vertex has at most T chunks the two parts never share a tile, and its chunks are numbered by tile,
+// so they are summed in list order whatever slot they sit in.  The cells are then written lane = cell (coalesced
+// stores), each lane finding its vertex by bisection of the prefix sums.
+__global__ void __launch_bounds__(256)
 resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
+    __shared__ unsigned s_pre[4][RES_MAX_OWNV + 1], s_k0[4][RES_MAX_OWNV], s_len[4][RES_MAX_OWNV];
     if (!R.flags[1]) return;
     const int frame = blockIdx.y;
     const int nb = R.n_bands, B = R.B;
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 4 + wv;
     if (idx >= B * nb) return;
     const int j = idx / nb, b = idx - j * nb;
     const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
@@ -1429,41 +1432,59 @@ resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
     const unsigned n_own = R.blk_nown[(size_t)frame * RES_MAXB + j];
     const unsigned short* verts = R.blk_verts + ((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV;
     const unsigned base = (unsigned)frame * (unsigned)L.N * 7u;   // the frame's first entry (csr_scan_kernel)
+    unsigned* pre = s_pre[wv]; unsigned* k0s = s_k0[wv]; unsigned* lens = s_len[wv];
+    unsigned run = 0, hmax = 0;
+    unsigned any_k0 = 0xFFFFFFFFu;    // an entry of this band: what an unused cell points at (weight 0)
+    for (unsigned u0 = 0; u0 < n_own; u0 += 64) {
+        const unsigned u = u0 + lane;
+        unsigned k0 = 0, len = 0;
+        if (u < n_own) { unsigned k1; resident_piece(L, R.band_wb, f0, Mf, verts[u], b, k0, k1); len = k1 - k0; }
+        const unsigned ch = (len + 63u) >> 6;
+        unsigned incl = ch;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (u < n_own) { pre[u] = run + incl - ch; k0s[u] = k0; lens[u] = len; }
+        hmax = len > hmax ? len : hmax;
+        const unsigned long long has = __ballot(ch != 0u);
+        if (any_k0 == 0xFFFFFFFFu && has) any_k0 = __shfl(k0, __ffsll((long long)has) - 1, 64);
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) pre[n_own] = run;
+    for (int o = 32; o > 0; o >>= 1) { const unsigned m2 = __shfl_xor(hmax, o, 64); hmax = m2 > hmax ? m2 : hmax; }
+    hmax = hmax > 64u ? 64u : hmax;   // height of the band's tiles for the adder (16 / 32 / 64 adds)
+    __builtin_amdgcn_wave_barrier();   // (one wave: its LDS writes are in order before the reads below)
     unsigned* info = R.tinfo + (size_t)frame * R.cap_tiles + t0;
-    for (unsigned t = 0; t < T; t++) info[t] = (unsigned)b << 16;
-    unsigned slot = 0, x = 0;        // next free cell
-    unsigned any_k0 = 0xFFFFFFFFu;   // an entry of this band: what an unused cell points at (weight 0)
-    auto cell = [&](unsigned s, unsigned t, unsigned u, unsigned at, unsigned n) {
+    for (unsigned t = lane; t < T; t += 64) info[t] = ((unsigned)b << 16) | hmax;
+    for (unsigned q = lane; q < 7u * T; q += 64) {
+        unsigned u = n_own, at = any_k0, n = 0;
+        if (q < run) {
+            unsigned lo = 0, hi = n_own;   // the vertex with pre[u] <= q < pre[u + 1]
+            while (hi - lo > 1u) { const unsigned mid = (lo + hi) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid; }
+            u = lo;
+            const unsigned p = pre[u], ch = pre[u + 1] - p, i = q - p;
+            const unsigned room = T - p % T;                       // cells left in the slot where the vertex starts
+            const unsigned wrap = ch > room ? ch - room : 0u;      // chunks at the top of the next slot: the FIRST ones (lower tiles)
+            const unsigned chunk = i < room ? wrap + i : i - room;
+            const unsigned len = lens[u];
+            n = len - 64u * chunk < 64u ? len - 64u * chunk : 64u;
+            at = k0s[u] + 64u * chunk;
+        }
+        const unsigned s = q / T, t = q - s * T;
         R.tdesc[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = ((at - base) << 7) | n;
         R.tvl[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = (unsigned short)u;
-        const unsigned cur = info[t];
-        if ((cur & 255u) < n) info[t] = (cur & ~255u) | n;
-    };
-    for (unsigned u = 0; u < n_own; u++) {
-        unsigned k0, k1;
-        resident_piece(L, R.band_wb, f0, Mf, verts[u], b, k0, k1);
-        const unsigned len = k1 - k0, ch = (len + 63u) >> 6;
-        if (!ch) continue;
-        if (any_k0 == 0xFFFFFFFFu) any_k0 = k0;
-        const unsigned room = T - x;            // cells left in this slot
-        const unsigned wrap = ch > room ? ch - room : 0u;   // chunks that go to the top of the next slot: the FIRST ones (lower tiles)
-        for (unsigned q = 0; q < ch; q++) {
-            const unsigned n = len - 64u * q < 64u ? len - 64u * q : 64u;
-            if (q < wrap) cell(slot + 1u, q, u, k0 + 64u * q, n);
-            else cell(slot, x + (q - wrap), u, k0 + 64u * q, n);
-        }
-        if (wrap) { slot++; x = wrap; }
-        else { x += ch; if (x == T) { slot++; x = 0; } }
     }
-    for (; slot < 7u; slot++, x = 0)
-        for (; x < T; x++) cell(slot, x, n_own, any_k0, 0u);
 }
 
 void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStream_t s) {
     (void)hipMemsetAsync(R.flags, 0, 2 * sizeof(int), s);
-    resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(RES_PLAN_THREADS), 0, s>>>(L, R);
+    // dynamic LDS of the planner: tile sums [B][n_bands] words + the heavy table, inside the 64 KB a block gets by default
+    const size_t t_bytes = (size_t)R.B * R.n_bands * 4;
+    const size_t fixed = 8192 + 4096 + RES_MAXB * RES_MAX_OWNV * 2 + 1024;
+    int heavy_cap = RES_HEAVY_MAX;
+    while (heavy_cap > 8 && fixed + t_bytes + (size_t)heavy_cap * R.n_bands > 60000) heavy_cap -= 8;
+    const size_t dyn = t_bytes + (size_t)heavy_cap * R.n_bands + 16;
+    resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(RES_PLAN_THREADS), dyn, s>>>(L, R, heavy_cap);
     resident_seal_kernel<<<dim3(1), dim3(1), 0, s>>>(L, R);
-    resident_fill_kernel<<<dim3((unsigned)((R.B * R.n_bands + 63) / 64), (unsigned)L.n_frames), dim3(64), 0, s>>>(L, R);
+    resident_fill_kernel<<<dim3((unsigned)((R.B * R.n_bands + 3) / 4), (unsigned)L.n_frames), dim3(256), 0, s>>>(L, R);
 }
 
 // The splat over the schedule.  Block (frame, j): 7 producer waves + the adder, as in splat_group_kernel; the tile

@@ -86,7 +86,6 @@ struct SplatResidentDev {
     unsigned short* blk_verts;   // [n_frames][RES_MAXB][RES_MAX_OWNV]: frame-local vertex of each block-local one
     unsigned* blk_nown;          // [n_frames][RES_MAXB]
     unsigned* jb_tile;           // [n_frames][RES_MAXB][n_bands + 1]: first tile of (block, band), relative to the frame
-    unsigned char* heavy_ch;     // plan scratch [n_frames][512][n_bands]: chunks per band of the frame's heaviest vertices
     unsigned* prog;              // [2 scratch slots][n_frames][RES_MAXB]: launch tag << 16 | band reached
     int* flags;                  // [0] frames the planner could not handle, [1] = 1: schedule valid
     unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) 8 words: start, end, tiles, ticks spent waiting for the pace (10 ns ticks), shader clocks

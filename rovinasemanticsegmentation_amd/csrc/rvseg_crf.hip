@@ -17,7 +17,7 @@ struct LatticeBufs {
     DevBuf q_items, q_cnt, q_off, q_small, q_vprog, q_trace;   // band-major splat queue (RVSEG_SPLAT_QUEUE=1)
     SplatQueueDev queue{};
     bool queue_on = false;
-    DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_heavy, r_trace;   // resident band schedule of the splat
+    DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_trace;   // resident band schedule of the splat
     SplatResidentDev resident{};
     bool resident_on = false;
     LatticeDev dev{};
@@ -59,7 +59,7 @@ static void lattice_free(LatticeBufs& b) {
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
                      &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist,
                      &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace,
-                     &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_heavy, &b.r_trace};
+                     &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_trace};
     for (DevBuf* x : all) dev_free(*x);
 }
 
@@ -255,8 +255,6 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
                 R.prog = sm;
                 R.blk_verts = b.r_verts.as<unsigned short>();
                 R.jb_tile = b.r_jb.as<unsigned>();
-                if ((st = dev_reserve(ctx, b.r_heavy, (size_t)n_frames * 512 * R.n_bands)) != RVSEG_OK) return st;
-                R.heavy_ch = b.r_heavy.as<unsigned char>();
                 R.trace = nullptr;
                 if (std::getenv("RVSEG_SPLAT_RESIDENT_TRACE")) {
                     if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 64)) != RVSEG_OK) return st;
