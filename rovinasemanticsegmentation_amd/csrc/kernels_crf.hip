@@ -766,21 +766,20 @@ static_assert(SPLAT_RE % SPLAT_RR == 0, "ring positions are compile-time: the ro
 // at the price of 7/6 as many block-steps; chunks with many frames are bandwidth bound and keep GV = G.
 // FAST: the input is this library's own Q * norm (finite, >= 0) in one contiguous [point][C] matrix: a padding lane's
 // product is 0 * x = +0 by itself (no select), and the row address needs no per-frame split.
-template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
-__global__ void __launch_bounds__((GV + 1) * 64)
-splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int band) {
+// One item of the list-major walk: G vertices of one frame, whole lists (or their piece inside `band`).  The kernel
+// below runs one item per block; the resident kernel falls back to a loop over these items when its planner gave up.
+template <int MODE, int CC, bool FULL, int GV, bool FAST>
+__device__ __forceinline__ void splat_group_item(const LatticeDev& L, const ValueView& src, int C, int c0, int n_store, float* __restrict__ values,
+                                                 int band, unsigned item, float (*prod)[GV][CC][68]) {
     constexpr int G = GV;
     constexpr int AW = (GV < SplatGroup<CC>::G && GV >= 4) ? 3 : GV;   // the adder's wave index
-    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];  // 16-B aligned rows, 4-bank skew
-    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
-    if (L.skip_if_queue && L.skip_if_queue[0]) return;   // the band-major queue schedule did this splat
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // block b -> XCD group b % n_groups (the dispatcher deals blocks round-robin over the 8 XCDs), item
+    // item b -> XCD group b % n_groups (the dispatcher deals blocks round-robin over the 8 XCDs), item
     // b / n_groups inside it.  A group owns the frames f = g, g + n_groups, ...: all readers of a
     // frame's Q rows share one L2.  Item j = (rank r, frame slot q): the r-th heaviest G vertices of
     // that frame -- every frame's heaviest vertices are dispatched first.
-    const unsigned g = blockIdx.x % (unsigned)L.n_groups, j = blockIdx.x / (unsigned)L.n_groups;
+    const unsigned g = item % (unsigned)L.n_groups, j = item / (unsigned)L.n_groups;
     const unsigned nfg = ((unsigned)L.n_frames - g + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;   // frames of this group
     if (nfg == 0) return;
     const unsigned r = j / nfg, frame = g + (j - r * nfg) * (unsigned)L.n_groups;
@@ -904,6 +903,15 @@ splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, floa
     }
 }
 
+template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
+__global__ void __launch_bounds__((GV + 1) * 64)
+splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int band) {
+    __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][68];  // 16-B aligned rows, 4-bank skew
+    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
+    if (L.skip_if_queue && L.skip_if_queue[0]) return;   // the band-major queue schedule did this splat
+    splat_group_item<MODE, CC, FULL, GV, FAST>(L, src, C, c0, n_store, values, band, blockIdx.x, prod);
+}
+
 template <int MODE, int CC, int GV, bool FAST>
 static void splat_group_launch_g(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
     constexpr int G = GV;
@@ -955,13 +963,8 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
     if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && resident) {
-        // resident band schedule; the list-major launch behind it returns at once unless the planner gave up
+        // resident band schedule (the kernel walks the lists the list-major way itself should the planner have given up)
         splat_resident_launch(L, *resident, src.base, values, slot, s);
-        LatticeDev L2 = L;
-        L2.skip_if_queue = resident->flags + 1;
-        const int gv = splat_gv_choice(L);
-        if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L2, src, C, 0, 9, values, s);
-        else splat_group_launch_g<0, 9, 7, true>(L2, src, C, 0, 9, values, s);
         return;
     }
     if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
@@ -1500,13 +1503,22 @@ void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStr
 // depend on each other for their results.
 template <int CC, int RE, int RR>
 __global__ void __launch_bounds__(512)
-splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* __restrict__ values, unsigned tag, int slot) {
+splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* __restrict__ values, unsigned tag, int slot, unsigned n_items) {
     constexpr int G = 7, C = CC;
     static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
     __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
     __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile {info, vertex of slot 0 .. 6}
-    if (L.counters[1] || !R.flags[1]) return;
+    if (L.counters[1]) return;
+    if (!R.flags[1]) {
+        // the planner gave up on some frame (more vertices or tiles than its tables hold): this grid walks the lists
+        // the list-major way, G vertices per item
+        for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
+            splat_group_item<0, CC, true, G, true>(L, srcv, CC, 0, CC, values, 0, item, prod);
+            __syncthreads();
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // block b -> XCD b % NG; all B blocks of a frame on one XCD (frame f lives on XCD f % NG)
@@ -1728,9 +1740,14 @@ static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
     const unsigned NG = (unsigned)L.n_groups;
     const unsigned rounds = ((unsigned)L.n_frames + NG - 1u) / NG;
     g_resident_tag = (g_resident_tag % 0x7FFFu) + 1u;
-    const ValueView sv{const_cast<float*>(src), 0, 0};
-    if (resident_ring() == 8) splat_resident_kernel<9, 8, 4><<<dim3(rounds * (unsigned)R.B * NG), dim3(512), 0, s>>>(L, R, sv, values, g_resident_tag, slot);
-    else splat_resident_kernel<9, 16, 8><<<dim3(rounds * (unsigned)R.B * NG), dim3(512), 0, s>>>(L, R, sv, values, g_resident_tag, slot);
+    const ValueView sv{const_cast<float*>(src), (size_t)L.N * 9u, 0};
+    // items of the list-major walk, should the planner have given up (splat_group_launch_g's grid)
+    const unsigned nfg = ((unsigned)L.n_frames + NG - 1u) / NG;
+    const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
+    const unsigned n_items = nfg * (unsigned)((max_mf + 6) / 7) * NG;
+    const dim3 grid(rounds * (unsigned)R.B * NG), block(512);
+    if (resident_ring() == 8) splat_resident_kernel<9, 8, 4><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    else splat_resident_kernel<9, 16, 8><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
 }
 
 int csr_pix_per_block() { return CS_PIX; }
