@@ -274,6 +274,17 @@ static rvseg_status values_reserve(rvseg_ctx* ctx, CrfState* cs, long long m_bou
     return RVSEG_OK;
 }
 
+// the context's second CRF stream (the second label layer's mean field; the splat planner beside the normaliser)
+static rvseg_status second_stream(rvseg_ctx* ctx, CrfState* cs) {
+    if (cs->layer_stream) return RVSEG_OK;
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    RV_HIP(ctx, hipStreamCreateWithPriority(&cs->layer_stream, hipStreamNonBlocking, prio_hi));
+    RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_fork, hipEventDisableTiming));
+    RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_join, hipEventDisableTiming));
+    return RVSEG_OK;
+}
+
 // Permutohedral::init + the normaliser of DenseKernel::initLattice (pairwise.cpp:40-56)
 static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, const FeatureSource& fs, hipStream_t s) {
     const LatticeDev& L = b.dev;
@@ -298,19 +309,28 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
         launch_queue_build(L, b.queue, s);
         tr("queue");
     }
+    rvseg_status st;
+    bool plan_forked = false;
     if (b.resident_on) {
-        RV_HIP(ctx, hipMemsetAsync(b.resident.prog, 0, 2 * (size_t)L.n_frames * RES_MAXB * 4, s));
-        launch_resident_plan(L, b.resident, s);
+        // the splat's band schedule needs the sorted lists only, like the normaliser below: it is planned beside it
+        if ((st = second_stream(ctx, cs)) != RVSEG_OK) return st;
+        RV_HIP(ctx, hipEventRecord(cs->layer_fork, s));
+        RV_HIP(ctx, hipStreamWaitEvent(cs->layer_stream, cs->layer_fork, 0));
+        RV_HIP(ctx, hipMemsetAsync(b.resident.prog, 0, 2 * (size_t)L.n_frames * RES_MAXB * 4, cs->layer_stream));
+        launch_resident_plan(L, b.resident, cs->layer_stream);
+        RV_HIP(ctx, hipEventRecord(cs->layer_join, cs->layer_stream));
+        plan_forked = true;
         tr("resident plan");
     }
-    rvseg_status st = values_reserve(ctx, cs, L.m_bound, 1);
-    if (st != RVSEG_OK) return st;
+    st = values_reserve(ctx, cs, L.m_bound, 1);
+    if (st != RVSEG_OK) { if (plan_forked) (void)hipStreamWaitEvent(s, cs->layer_join, 0); return st; }
     // norm = lattice.compute(ones) through seqCompute (1 row), then 1/sqrt(norm + 1e-20)
     ValueView none{nullptr, 0, 0};
     launch_splat(L, none, 1, 2, cs->val_a.as<float>(), s);
     float* blurred = launch_blur(L, 1, true, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s, true);
     launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
     tr("normaliser");
+    if (plan_forked) RV_HIP(ctx, hipStreamWaitEvent(s, cs->layer_join, 0));
     RV_HIP(ctx, hipGetLastError());
     b.built = true;
     return RVSEG_OK;
@@ -428,13 +448,8 @@ static rvseg_status layer_stream_fork(rvseg_ctx* ctx, CrfState* cs, hipStream_t 
     *s2 = s;
     static const bool serial = std::getenv("RVSEG_NO_LAYER_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_LAYER_OVERLAP")) != 0;
     if (n_layers < 2 || serial) return RVSEG_OK;
-    if (!cs->layer_stream) {
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        RV_HIP(ctx, hipStreamCreateWithPriority(&cs->layer_stream, hipStreamNonBlocking, prio_hi));
-        RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_fork, hipEventDisableTiming));
-        RV_HIP(ctx, hipEventCreateWithFlags(&cs->layer_join, hipEventDisableTiming));
-    }
+    rvseg_status st = second_stream(ctx, cs);
+    if (st != RVSEG_OK) return st;
     RV_HIP(ctx, hipEventRecord(cs->layer_fork, s));
     RV_HIP(ctx, hipStreamWaitEvent(cs->layer_stream, cs->layer_fork, 0));
     *s2 = cs->layer_stream;
