@@ -54,7 +54,7 @@ PIPELINE_BYTES_PER_PX = 1350.0       # whole RF + 5-iteration CRF path, SURVEY.m
 
 # stage name -> kernel whose PMC counters (profiles/*_pmc_batch64.json, collected with separate
 # rocprofv3 --pmc passes of this very command, profiles/scripts/pmc.sh) give the HBM traffic per launch
-STAGE_KERNEL = {"splat": "rvseg::splat_group_kernel<0, 9, true>", "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
+STAGE_KERNEL = {"splat": ("rvseg::splat_resident_kernel<9", "rvseg::splat_group_kernel<0, 9, true>"), "mf_update": "rvseg::mf_update_kernel<false, 9, 7>",
                 "rf_frames": "rvseg::rf_frames_lazy_kernel", "normal_feature": "rvseg::normal_feature_tiled_kernel",
                 "upsample_pack": "rvseg::upsample_pack_kernel<9>", "softmax": "rvseg::softmax_unary_kernel<9>",
                 "prep": "rvseg::prep_kernel"}
@@ -82,8 +82,16 @@ def pmc_traffic(stage):
         return None
     with open(f) as fh:
         d = json.load(fh)
-    want = STAGE_KERNEL[stage].rstrip(">")   # template arguments added later (block shape ...) follow the ones named here
-    r = next((v for k, v in sorted(d.items()) if k == STAGE_KERNEL[stage] or k.startswith(want + ",")), None)
+    # several candidates: the first that ran (the resident band schedule, else the list-major walk); template
+    # arguments added later (block shape ...) follow the ones named here
+    names = STAGE_KERNEL[stage] if isinstance(STAGE_KERNEL[stage], tuple) else (STAGE_KERNEL[stage],)
+    r = None
+    for name in names:
+        want = name.rstrip(">")
+        r = next((v for k, v in sorted(d.items())
+                  if (k == name or k.startswith(want + ",")) and v.get("avg_us_profiled", 0) > 50.0), None)
+        if r:
+            break
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
         return None
     factor = 2.0

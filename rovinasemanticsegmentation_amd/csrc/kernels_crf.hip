@@ -1508,7 +1508,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
     static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
     __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
-    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile {info, vertex of slot 0 .. 6}
+    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile and slot, vertex | height << 9 | band << 16
     if (L.counters[1]) return;
     if (!R.flags[1]) {
         // the planner gave up on some frame (more vertices or tiles than its tables hold): this grid walks the lists
@@ -1616,9 +1616,10 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         auto batch_store = [&](unsigned first) {
             const bool in = first + (unsigned)lane < n_t;
             unsigned* row = &ainfo[(first >> 6) & 1u][lane][0];
-            row[0] = pend[0];
+            // one word per slot: vertex | height << 9 | band << 16 (a lane reads ONE word per tile)
+            const unsigned hb = ((pend[0] & 255u) << 9) | ((pend[0] >> 16) << 16);
 #pragma unroll
-            for (int i = 0; i < G; i++) row[1 + i] = in ? pend[1 + i] : n_own;
+            for (int i = 0; i < G; i++) row[i] = (in ? pend[1 + i] : n_own) | hb;
         };
         auto poll = [&]() -> unsigned { return __hip_atomic_load(&prog[(unsigned)lane < B ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         const unsigned tagv = tag << 16;
@@ -1630,14 +1631,12 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         unsigned cur_vl = n_own, cur_band = 0u;
         bool pacing = R.window >= 0;
         float acc = 0.0f;
-        unsigned v_n = n_own, info_n = 0u;
-        // issues the two table reads of tile t (results in v_n / info_n: used after the next barrier)
+        unsigned w_n = n_own;
+        // issues the table read of tile t (used after the next barrier)
         auto prep = [&](unsigned t) {
             if (t >= n_t) return;
             if ((t & 63u) == 0u && t) { batch_store(t); batch_load(t + 64u); }
-            const unsigned* row = &ainfo[(t >> 6) & 1u][t & 63u][0];
-            info_n = row[0];
-            v_n = live ? row[1 + gi] : n_own;
+            w_n = ainfo[(t >> 6) & 1u][t & 63u][gi];
         };
         auto pace = [&](unsigned band) {
             cur_band = band;
@@ -1661,10 +1660,11 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
             polled = poll();   // consumed at the next band
         };
         prep(0u);
-        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(info_n) >> 16; if (b0 != cur_band) pace(b0); }
+        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(w_n) >> 16; if (b0 != cur_band) pace(b0); }
         __syncthreads();
         for (unsigned t = 0; t < n_t; t++) {
-            const unsigned nmax = __builtin_amdgcn_readfirstlane(info_n) & 255u;
+            const unsigned nmax = (__builtin_amdgcn_readfirstlane(w_n) >> 9) & 127u;
+            const unsigned v_n = live ? (w_n & 511u) : n_own;
             // the slot's vertex changed: park the sum, fetch the other one.  Store before load, one wave: a chain that
             // moved here from another slot of the previous tile is handed over in order.
             if (v_n != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v_n * CC + c]; cur_vl = v_n; }
@@ -1691,7 +1691,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             }
-            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(info_n) >> 16; if (bn != cur_band) pace(bn); }
+            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(w_n) >> 16; if (bn != cur_band) pace(bn); }
             __syncthreads();
         }
         accs[cur_vl * CC + c] = acc;
