@@ -953,6 +953,7 @@ static int splat_gv_choice(const LatticeDev& L) {
     return L.n_frames <= 16 ? 6 : 7;
 }
 
+template <int CC>
 static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s);
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
@@ -962,9 +963,10 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         return;
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
-    if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && resident) {
+    if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8) && resident) {
         // resident band schedule (the kernel walks the lists the list-major way itself should the planner have given up)
-        splat_resident_launch(L, *resident, src.base, values, slot, s);
+        if (C == 9) splat_resident_launch<9>(L, *resident, src.base, values, slot, s);
+        else splat_resident_launch<8>(L, *resident, src.base, values, slot, s);
         return;
     }
     if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
@@ -1508,7 +1510,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
     static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
     __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
     __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
-    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile and slot, vertex | height << 9 | band << 16
+    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile and slot, vertex | height << 10 | band << 17
     if (L.counters[1]) return;
     if (!R.flags[1]) {
         // the planner gave up on some frame (more vertices or tiles than its tables hold): this grid walks the lists
@@ -1616,8 +1618,8 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         auto batch_store = [&](unsigned first) {
             const bool in = first + (unsigned)lane < n_t;
             unsigned* row = &ainfo[(first >> 6) & 1u][lane][0];
-            // one word per slot: vertex | height << 9 | band << 16 (a lane reads ONE word per tile)
-            const unsigned hb = ((pend[0] & 255u) << 9) | ((pend[0] >> 16) << 16);
+            // one word per slot: vertex | height << 10 | band << 17 (a lane reads ONE word per tile)
+            const unsigned hb = ((pend[0] & 255u) << 10) | ((pend[0] >> 16) << 17);
 #pragma unroll
             for (int i = 0; i < G; i++) row[i] = (in ? pend[1 + i] : n_own) | hb;
         };
@@ -1660,11 +1662,11 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
             polled = poll();   // consumed at the next band
         };
         prep(0u);
-        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(w_n) >> 16; if (b0 != cur_band) pace(b0); }
+        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(w_n) >> 17; if (b0 != cur_band) pace(b0); }
         __syncthreads();
         for (unsigned t = 0; t < n_t; t++) {
-            const unsigned nmax = (__builtin_amdgcn_readfirstlane(w_n) >> 9) & 127u;
-            const unsigned v_n = live ? (w_n & 511u) : n_own;
+            const unsigned nmax = (__builtin_amdgcn_readfirstlane(w_n) >> 10) & 127u;
+            const unsigned v_n = live ? (w_n & 1023u) : n_own;
             // the slot's vertex changed: park the sum, fetch the other one.  Store before load, one wave: a chain that
             // moved here from another slot of the previous tile is handed over in order.
             if (v_n != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v_n * CC + c]; cur_vl = v_n; }
@@ -1691,7 +1693,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             }
-            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(w_n) >> 16; if (bn != cur_band) pace(bn); }
+            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(w_n) >> 17; if (bn != cur_band) pace(bn); }
             __syncthreads();
         }
         accs[cur_vl * CC + c] = acc;
@@ -1736,18 +1738,19 @@ int resident_block_capacity() {
     return cap[which];
 }
 
+template <int CC>
 static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
     const unsigned NG = (unsigned)L.n_groups;
     const unsigned rounds = ((unsigned)L.n_frames + NG - 1u) / NG;
     g_resident_tag = (g_resident_tag % 0x7FFFu) + 1u;
-    const ValueView sv{const_cast<float*>(src), (size_t)L.N * 9u, 0};
+    const ValueView sv{const_cast<float*>(src), (size_t)L.N * (unsigned)CC, 0};
     // items of the list-major walk, should the planner have given up (splat_group_launch_g's grid)
     const unsigned nfg = ((unsigned)L.n_frames + NG - 1u) / NG;
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned n_items = nfg * (unsigned)((max_mf + 6) / 7) * NG;
     const dim3 grid(rounds * (unsigned)R.B * NG), block(512);
-    if (resident_ring() == 8) splat_resident_kernel<9, 8, 4><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
-    else splat_resident_kernel<9, 16, 8><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    if (resident_ring() == 8) splat_resident_kernel<CC, 8, 4><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    else splat_resident_kernel<CC, 16, 8><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
 }
 
 int csr_pix_per_block() { return CS_PIX; }

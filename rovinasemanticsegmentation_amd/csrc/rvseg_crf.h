@@ -75,7 +75,7 @@ struct SplatQueueDev {
 // different tiles, in order (wrap-around rule: tiles = max(longest vertex, chunks / 7)); which vertex a slot serves
 // changes from tile to tile, so the running sums live in LDS and a slot swaps its sum when its vertex changes.
 constexpr int RES_MAXB = 16;          // blocks per frame at most
-constexpr int RES_MAX_OWNV = 256;     // vertices a block can own (their running sums live in LDS)
+constexpr int RES_MAX_OWNV = 640;     // vertices a block can own (their running sums live in LDS): a 2 048-vertex frame on 4 blocks
 constexpr int RES_MAX_VERTS = 2048;   // vertices of a frame the planner handles
 constexpr int RES_MAX_BANDS = 512;
 struct SplatResidentDev {

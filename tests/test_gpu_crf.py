@@ -288,3 +288,33 @@ def test_resident_band_splat_falls_back_when_the_planner_gives_up(gpu_ctx_factor
     for i in range(2):
         post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
         assert np.array_equal(out["marginals"][i], marg), i
+
+
+@pytest.mark.parametrize("scale,B", [(1.0, 4), (3.0, 4), (3.0, 2)])
+def test_resident_band_splat_two_layers_and_fine_lattices(gpu_ctx_factory, oracle, scale, B):
+    """The resident schedule for the 8-class layer too (two label layers: an 8- and a 9-class mean field over one
+    lattice, on two streams), and on lattices with many more vertices per frame than the default kernel widths give
+    (both pairwise kernels scaled by 3: a finer lattice; B = 2 makes a block own hundreds of vertices)."""
+    blob = synthetic.make_forest_bytes(seed=31, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
+    forest = oracle.Forest(blob)
+    W, H = 320, 240
+    rgb, depth = synthetic.make_batch(8, W, H, holes=True, start=11)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, dcrf_iterations=2)
+    p = oracle.default_params(**kw)
+    kw["dcrf_xyz_kernel"] = p.dcrf_xyz_kernel * scale
+    kw["dcrf_rgb_kernel"] = p.dcrf_rgb_kernel * scale
+    p = oracle.default_params(**kw)
+    env = {"RVSEG_SPLAT_RESIDENT": "2", "RVSEG_SPLAT_RESIDENT_B": str(B)}
+    os.environ.update(env)
+    try:
+        ctx = gpu_ctx_factory(multi_layer=1, use_dense_crf=1, label_mode=1, unknown_label=[7, 8], max_batch=8, lattice_capacity_log2=13, **kw)
+        ctx.forest_load(blob)
+        out = ctx.segment_frames(rgb, depth, calib)
+    finally:
+        for k in env:
+            del os.environ[k]
+    for i in range(8):
+        post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[7, 8])
+        assert np.array_equal(out["marginals"][i], marg), i
+        assert np.array_equal(out["labels"][i].ravel(), lab), i
