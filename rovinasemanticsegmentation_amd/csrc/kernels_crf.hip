@@ -1271,6 +1271,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
     const int f1 = L.fstart[frame + 1] < Mtot ? L.fstart[frame + 1] : Mtot;
     const int Mf = f1 - f0, nb = R.n_bands, B = R.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned clog = (unsigned)R.chunk_log2, cmask = (1u << clog) - 1u;   // entries per chunk: 64 or 128
     unsigned* T = plan_lds;                                               // [B][nb]: greedy: (sum of chunks) << 8 | longest; then tiles, then their scan
     unsigned char* hc = reinterpret_cast<unsigned char*>(plan_lds + B * nb);   // [heavy_cap][nb]
     if (tid == 0) { bad = 0; choice = 0; }
@@ -1291,7 +1292,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
         const int b = i / Mf, lv = i - b * Mf;   // consecutive threads: consecutive vertices of one band (the table's row)
         unsigned k0, k1;
         resident_piece(L, R.band_wb, f0, Mf, lv, b, k0, k1);
-        const unsigned ch = (k1 - k0 + 63u) >> 6;
+        const unsigned ch = (k1 - k0 + cmask) >> clog;
         if (ch) atomicAdd(&chv[lv], ch);
     }
     __syncthreads();
@@ -1299,7 +1300,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
     const int wpj = (RES_PLAN_THREADS / 64) / B;              // waves per block (B <= 16)
     const int my_j = wave % B, my_part = wave / B;
     // heavy = at least 12 chunks; `vorder` is sorted by length, so they are (about) a prefix of it: its length is counted
-    if (tid < heavy_cap && tid < Mf && chv[lvo[tid]] >= 12u) atomicAdd(&choice, 1);
+    if (tid < heavy_cap && tid < Mf && chv[lvo[tid]] >= (12u >> (clog - 6))) atomicAdd(&choice, 1);
     __syncthreads();
     const int n_heavy = choice;
     __syncthreads();
@@ -1308,7 +1309,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
         const int k = i / nb, b = i - k * nb;
         unsigned k0, k1;
         resident_piece(L, R.band_wb, f0, Mf, lvo[k], b, k0, k1);
-        hc[i] = (unsigned char)((k1 - k0 + 63u) >> 6);
+        hc[i] = (unsigned char)((k1 - k0 + cmask) >> clog);
     }
     __syncthreads();
     for (int k = 0; k < n_heavy; k++) {
@@ -1368,7 +1369,7 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
         for (unsigned u = nheavy[j] + lane; u < nown[j]; u += 64) {
             unsigned k0, k1;
             resident_piece(L, R.band_wb, f0, Mf, own[j][u], b, k0, k1);
-            const unsigned ch = (k1 - k0 + 63u) >> 6;
+            const unsigned ch = (k1 - k0 + cmask) >> clog;
             sum += ch;
             mx = ch > mx ? ch : mx;
         }
@@ -1438,13 +1439,14 @@ resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
     const unsigned short* verts = R.blk_verts + ((size_t)frame * RES_MAXB + j) * RES_MAX_OWNV;
     const unsigned base = (unsigned)frame * (unsigned)L.N * 7u;   // the frame's first entry (csr_scan_kernel)
     unsigned* pre = s_pre[wv]; unsigned* k0s = s_k0[wv]; unsigned* lens = s_len[wv];
+    const unsigned clog = (unsigned)R.chunk_log2, cmask = (1u << clog) - 1u, CH = 1u << clog;
     unsigned run = 0, hmax = 0;
     unsigned any_k0 = 0xFFFFFFFFu;    // an entry of this band: what an unused cell points at (weight 0)
     for (unsigned u0 = 0; u0 < n_own; u0 += 64) {
         const unsigned u = u0 + lane;
         unsigned k0 = 0, len = 0;
         if (u < n_own) { unsigned k1; resident_piece(L, R.band_wb, f0, Mf, verts[u], b, k0, k1); len = k1 - k0; }
-        const unsigned ch = (len + 63u) >> 6;
+        const unsigned ch = (len + cmask) >> clog;
         unsigned incl = ch;
         for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
         if (u < n_own) { pre[u] = run + incl - ch; k0s[u] = k0; lens[u] = len; }
@@ -1455,7 +1457,7 @@ resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
     }
     if (lane == 0) pre[n_own] = run;
     for (int o = 32; o > 0; o >>= 1) { const unsigned m2 = __shfl_xor(hmax, o, 64); hmax = m2 > hmax ? m2 : hmax; }
-    hmax = hmax > 64u ? 64u : hmax;   // height of the band's tiles for the adder (16 / 32 / 64 adds)
+    hmax = hmax > CH ? CH : hmax;   // height of the band's tiles for the adder (16 / 32 / 64 / 128 adds)
     __builtin_amdgcn_wave_barrier();   // (one wave: its LDS writes are in order before the reads below)
     unsigned* info = R.tinfo + (size_t)frame * R.cap_tiles + t0;
     for (unsigned t = lane; t < T; t += 64) info[t] = ((unsigned)b << 16) | hmax;
@@ -1470,11 +1472,11 @@ resident_fill_kernel(LatticeDev L, SplatResidentDev R) {
             const unsigned wrap = ch > room ? ch - room : 0u;      // chunks at the top of the next slot: the FIRST ones (lower tiles)
             const unsigned chunk = i < room ? wrap + i : i - room;
             const unsigned len = lens[u];
-            n = len - 64u * chunk < 64u ? len - 64u * chunk : 64u;
-            at = k0s[u] + 64u * chunk;
+            n = len - CH * chunk < CH ? len - CH * chunk : CH;
+            at = k0s[u] + CH * chunk;
         }
         const unsigned s = q / T, t = q - s * T;
-        R.tdesc[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = ((at - base) << 7) | n;
+        R.tdesc[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = ((at - base) << 8) | n;
         R.tvl[((size_t)frame * 7 + s) * R.cap_tiles + t0 + t] = (unsigned short)u;
     }
 }
@@ -1503,20 +1505,24 @@ void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStr
 // at the tile's barrier) while any block of its frame is more than `window` bands behind; the check uses the progress
 // words fetched one band earlier, so it costs no round trip unless it waits, and the wait is bounded -- blocks never
 // depend on each other for their results.
-template <int CC, int RE, int RR>
+template <int CC, int RE, int RR, int TH>   // TH: entries per slot and tile (64 or 128)
 __global__ void __launch_bounds__(512)
 splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* __restrict__ values, unsigned tag, int slot, unsigned n_items) {
     constexpr int G = 7, C = CC;
-    static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0, "block shape");
-    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
-    __shared__ float accs[(RES_MAX_OWNV + 1) * CC];
-    __shared__ unsigned ainfo[2][64][8];   // the adder's table: per tile and slot, vertex | height << 10 | band << 17
+    static_assert(CC * G <= 64 && (RE == 16 || RE == 8) && RE % RR == 0 && (TH == 64 || TH == 128), "block shape");
+    constexpr int NH = TH / 64;        // entries per lane and tile
+    constexpr int ROW = TH + 4;        // product row: 16-B aligned, 4-bank skew
+    // dynamic LDS (more than 64 KB for TH = 128): products [2][G][CC][ROW], running sums, the adder's table
+    extern __shared__ __attribute__((aligned(16))) float res_lds[];
+    float (*prod)[G][CC][ROW] = reinterpret_cast<float (*)[G][CC][ROW]>(res_lds);
+    float* accs = res_lds + 2 * G * CC * ROW;
+    unsigned (*ainfo)[64][8] = reinterpret_cast<unsigned (*)[64][8]>(accs + (RES_MAX_OWNV + 1) * CC);   // per tile and slot: vertex | height << 10 | band << 18
     if (L.counters[1]) return;
     if (!R.flags[1]) {
         // the planner gave up on some frame (more vertices or tiles than its tables hold): this grid walks the lists
         // the list-major way, G vertices per item
         for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
-            splat_group_item<0, CC, true, G, true>(L, srcv, CC, 0, CC, values, 0, item, prod);
+            splat_group_item<0, CC, true, G, true>(L, srcv, CC, 0, CC, values, 0, item, reinterpret_cast<float (*)[G][CC][68]>(res_lds));
             __syncthreads();
         }
         return;
@@ -1546,27 +1552,36 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
             const unsigned* D = R.tdesc + ((size_t)frame * 7 + wave) * R.cap_tiles + tb;
             const unsigned base = frame * (unsigned)L.N * 7u;   // the frame's first entry (csr_scan_kernel: every point has d + 1 entries)
             const unsigned klast = base + (unsigned)L.N * 7u - 1u;
-            float xr[RR][CC];
-            float w[RE];
-            unsigned pix[RE];
+            float xr[RR][NH][CC];
+            float w[RE][NH];
+            unsigned pix[RE][NH];
 #pragma unroll
-            for (int r = 0; r < RE; r++) { w[r] = 0.f; pix[r] = 0u; }
+            for (int r = 0; r < RE; r++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) { w[r][h] = 0.f; pix[r][h] = 0u; }
             auto load_desc = [&](unsigned first) -> unsigned {
                 const unsigned t = first + (unsigned)lane;
                 return D[t < n_t ? t : n_t - 1u];
             };
             unsigned dcur = load_desc(0u), dnxt = dcur;
             auto load_entries = [&](unsigned d, int slot_e) {
-                const unsigned n = d & 127u, last = n ? n - 1u : 0u;
-                unsigned k = base + (d >> 7) + ((unsigned)lane < last ? (unsigned)lane : last);
-                k = k < klast ? k : klast;
-                const uint2 e = L.csr_pw[k];
-                w[slot_e] = __uint_as_float(e.y);
-                pix[slot_e] = e.x;
+                const unsigned n = d & 255u, last = n ? n - 1u : 0u;
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    const unsigned i = (unsigned)lane + 64u * h;
+                    unsigned k = base + (d >> 8) + (i < last ? i : last);
+                    k = k < klast ? k : klast;
+                    const uint2 e = L.csr_pw[k];
+                    w[slot_e][h] = __uint_as_float(e.y);
+                    pix[slot_e][h] = e.x;
+                }
             };
             // (the rows come through a plain pointer: a const __restrict__ kernel argument makes the gathers invariant loads,
             // which the compiler then sinks to their use -- the whole prefetch distance lost)
-            auto gather_rows = [&](int eslot, int rslot) { load_row<CC>(srcv.base + (size_t)pix[eslot] * (unsigned)C, xr[rslot]); };
+            auto gather_rows = [&](int eslot, int rslot) {
+#pragma unroll
+                for (int h = 0; h < NH; h++) load_row<CC>(srcv.base + (size_t)pix[eslot][h] * (unsigned)C, xr[rslot][h]);
+            };
 #pragma unroll
             for (int i = 0; i < RE - 1; i++) load_entries(__builtin_amdgcn_readlane(dcur, i), i);
 #pragma unroll
@@ -1574,11 +1589,14 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
             auto stage = [&](unsigned t, auto S) -> bool {
                 constexpr int s = decltype(S)::value;
                 if (t >= n_t) return false;
-                const unsigned n = __builtin_amdgcn_readlane(dcur, s) & 127u;
-                const float wl = (unsigned)lane < n ? w[s] : 0.0f;
-                float (*pb)[68] = prod[t & 1u][wave];
+                const unsigned n = __builtin_amdgcn_readlane(dcur, s) & 255u;
+                float (*pb)[ROW] = prod[t & 1u][wave];
 #pragma unroll
-                for (int c = 0; c < CC; c++) pb[c][lane] = wl * xr[s % RR][c];   // +0 past the chunk (rows are finite)
+                for (int h = 0; h < NH; h++) {
+                    const float wl = (unsigned)lane + 64u * h < n ? w[s][h] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CC; c++) pb[c][lane + 64 * h] = wl * xr[s % RR][h][c];   // +0 past the chunk (rows are finite)
+                }
                 load_entries(__builtin_amdgcn_readlane(dcur, s + RE - 1), (s + RE - 1) % RE);
                 gather_rows((s + RR - 1) % RE, (s + RR - 1) % RR);
                 __syncthreads();
@@ -1618,8 +1636,8 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         auto batch_store = [&](unsigned first) {
             const bool in = first + (unsigned)lane < n_t;
             unsigned* row = &ainfo[(first >> 6) & 1u][lane][0];
-            // one word per slot: vertex | height << 10 | band << 17 (a lane reads ONE word per tile)
-            const unsigned hb = ((pend[0] & 255u) << 10) | ((pend[0] >> 16) << 17);
+            // one word per slot: vertex | height << 10 | band << 18 (a lane reads ONE word per tile)
+            const unsigned hb = ((pend[0] & 255u) << 10) | ((pend[0] >> 16) << 18);
 #pragma unroll
             for (int i = 0; i < G; i++) row[i] = (in ? pend[1 + i] : n_own) | hb;
         };
@@ -1662,16 +1680,33 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
             polled = poll();   // consumed at the next band
         };
         prep(0u);
-        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(w_n) >> 17; if (b0 != cur_band) pace(b0); }
+        if (n_t) { const unsigned b0 = __builtin_amdgcn_readfirstlane(w_n) >> 18; if (b0 != cur_band) pace(b0); }
         __syncthreads();
         for (unsigned t = 0; t < n_t; t++) {
-            const unsigned nmax = (__builtin_amdgcn_readfirstlane(w_n) >> 10) & 127u;
+            const unsigned nmax = (__builtin_amdgcn_readfirstlane(w_n) >> 10) & 255u;
             const unsigned v_n = live ? (w_n & 1023u) : n_own;
             // the slot's vertex changed: park the sum, fetch the other one.  Store before load, one wave: a chain that
             // moved here from another slot of the previous tile is handed over in order.
             if (v_n != cur_vl) { accs[cur_vl * CC + c] = acc; acc = accs[v_n * CC + c]; cur_vl = v_n; }
             const float* pr = prod[t & 1u][gi][c];
-            if (nmax > 32u) {
+            bool done = false;
+            if constexpr (TH == 128) {
+                if (nmax > 64u) {
+                    float4 q[16], q2[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) q2[i] = reinterpret_cast<const float4*>(pr)[16 + i];
+                    prep(t + 1u);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+#pragma unroll
+                    for (int i = 0; i < 16; i++) { acc += q2[i].x; acc += q2[i].y; acc += q2[i].z; acc += q2[i].w; }
+                    done = true;
+                }
+            }
+            if (done) {
+            } else if (nmax > 32u) {
                 float4 q[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
@@ -1693,7 +1728,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
 #pragma unroll
                 for (int i = 0; i < 4; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
             }
-            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(w_n) >> 17; if (bn != cur_band) pace(bn); }
+            if (t + 1u < n_t) { const unsigned bn = __builtin_amdgcn_readfirstlane(w_n) >> 18; if (bn != cur_band) pace(bn); }
             __syncthreads();
         }
         accs[cur_vl * CC + c] = acc;
@@ -1712,25 +1747,32 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
 
 static unsigned g_resident_tag = 0;
 
-static int resident_ring() {
-    const int ring = std::getenv("RVSEG_SPLAT_RESIDENT_RING") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_RING")) : 8;
-    return ring == 16 ? 16 : 8;
+static size_t resident_lds_bytes(int CC, int TH) {
+    return ((size_t)2 * 7 * CC * (TH + 4) + (size_t)(RES_MAX_OWNV + 1) * CC) * sizeof(float) + 2 * 64 * 8 * sizeof(unsigned);
+}
+
+// more than 64 KB of dynamic LDS has to be asked for, once per instantiation
+template <int CC, int TH>
+static bool resident_setup() {
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(splat_resident_kernel<CC, 8, 4, TH>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(CC, TH));
+    return e == hipSuccess;
 }
 
 static int g_resident_cus = 0;
-int resident_cu_count() { (void)resident_block_capacity(); return g_resident_cus; }
+int resident_cu_count() { (void)resident_block_capacity(64); return g_resident_cus; }
 
-int resident_block_capacity() {
+int resident_block_capacity(int chunk) {
     static int cap[2] = {-1, -1};
-    const int which = resident_ring() == 16 ? 1 : 0;
+    const int which = chunk == 128 ? 1 : 0;
     if (cap[which] < 0) {
         int dev = 0, per_cu = 0;
         hipDeviceProp_t pr;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipGetDeviceProperties(&pr, dev);
         if (e == hipSuccess) {
-            if (which) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 16, 8>, 512, 0);
-            else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4>, 512, 0);
+            if (which) e = resident_setup<9, 128>() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4, 128>, 512, resident_lds_bytes(9, 128)) : hipErrorUnknown;
+            else e = resident_setup<9, 64>() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4, 64>, 512, resident_lds_bytes(9, 64)) : hipErrorUnknown;
         }
         cap[which] = e == hipSuccess ? per_cu * pr.multiProcessorCount : 0;
         if (e == hipSuccess) g_resident_cus = pr.multiProcessorCount;
@@ -1749,8 +1791,11 @@ static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned n_items = nfg * (unsigned)((max_mf + 6) / 7) * NG;
     const dim3 grid(rounds * (unsigned)R.B * NG), block(512);
-    if (resident_ring() == 8) splat_resident_kernel<CC, 8, 4><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
-    else splat_resident_kernel<CC, 16, 8><<<grid, block, 0, s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    if (R.chunk_log2 == 7) {
+        if (resident_setup<CC, 128>()) splat_resident_kernel<CC, 8, 4, 128><<<grid, block, resident_lds_bytes(CC, 128), s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    } else {
+        if (resident_setup<CC, 64>()) splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+    }
 }
 
 int csr_pix_per_block() { return CS_PIX; }

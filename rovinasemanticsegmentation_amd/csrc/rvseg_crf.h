@@ -70,8 +70,8 @@ struct SplatQueueDev {
 // band of `band_wb` wave-blocks of points, so the d+1 readers of a point's row pass within a few bands of each other
 // and meet in the XCD's L2, while every chain stays inside one block (sums never travel between blocks: no hand-off,
 // no dependency -- the pacing is a hint, not a condition of correctness).  The walk is a list of tiles built once per
-// lattice.  A tile is one step of the block: seven slots, each up to 64 consecutive entries of one vertex.  Inside a
-// band the 64-entry chunks of the block's vertices are packed into the fewest tiles that keep a vertex's chunks in
+// lattice.  A tile is one step of the block: seven slots, each up to 64 (or 128) consecutive entries of one vertex.  Inside a
+// band the chunks of the block's vertices are packed into the fewest tiles that keep a vertex's chunks in
 // different tiles, in order (wrap-around rule: tiles = max(longest vertex, chunks / 7)); which vertex a slot serves
 // changes from tile to tile, so the running sums live in LDS and a slot swaps its sum when its vertex changes.
 constexpr int RES_MAXB = 16;          // blocks per frame at most
@@ -79,7 +79,7 @@ constexpr int RES_MAX_OWNV = 640;     // vertices a block can own (their running
 constexpr int RES_MAX_VERTS = 2048;   // vertices of a frame the planner handles
 constexpr int RES_MAX_BANDS = 512;
 struct SplatResidentDev {
-    unsigned* tdesc;             // [n_frames][7][cap_tiles]: (first entry - frame's first entry) << 7 | entries (0..64)
+    unsigned* tdesc;             // [n_frames][7][cap_tiles]: (first entry - frame's first entry) << 8 | entries (0..128)
     unsigned short* tvl;         // [n_frames][7][cap_tiles]: block-local vertex of the slot (n_own = nobody: entries is 0)
     unsigned* tinfo;             // [n_frames][cap_tiles]: band << 16 | most entries of a slot
     unsigned* blk_tile0;         // [n_frames][RES_MAXB + 1]: block j walks tiles [blk_tile0[j], blk_tile0[j + 1]) of its frame
@@ -90,6 +90,7 @@ struct SplatResidentDev {
     int* flags;                  // [0] frames the planner could not handle, [1] = 1: schedule valid
     unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) 8 words: start, end, tiles, ticks spent waiting for the pace (10 ns ticks), shader clocks
     int B, band_wb, n_bands, window;
+    int chunk_log2;              // entries per slot and tile: 2^6 or 2^7
     unsigned cap_tiles;
 };
 
@@ -143,7 +144,7 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
 // builds the resident band schedule from the counting-sort table (after launch_lattice_finish)
 void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& r, hipStream_t s);
 // how many blocks of the resident splat kernel fit on the device at once (0: unknown)
-int resident_block_capacity();
+int resident_block_capacity(int chunk);
 int resident_cu_count();
 // builds the band-major queue from the counting-sort table (after launch_lattice_finish)
 void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s);

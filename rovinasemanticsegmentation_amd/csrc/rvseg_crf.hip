@@ -217,10 +217,12 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     {
         const int res_env = std::getenv("RVSEG_SPLAT_RESIDENT") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT")) : 1;
         const int b_env = std::getenv("RVSEG_SPLAT_RESIDENT_B") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_B")) : 0;
-        const int band_env = std::getenv("RVSEG_SPLAT_RESIDENT_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_BAND")) : 8;
+        const int band_env = std::getenv("RVSEG_SPLAT_RESIDENT_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_BAND")) : 16;
         const int win_env = std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW")) : -1;   // measured: pacing costs more than its locality saves (the kernel is issue bound)
         const int min_frames = res_env > 1 ? 1 : 17;   // 2 = also for few frames (experiments)
-        const int capacity = resident_block_capacity();
+        const int chunk_env = std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK")) : 128;
+        const int chunk = chunk_env == 64 ? 64 : 128;
+        const int capacity = resident_block_capacity(chunk);
         // one block per CU measured best (the tile loop is bound by its own barrier-coupled latencies, a second block on
         // the CU slows both): B = CUs / frames, at least 2, at most 12
         int B = b_env > 0 ? b_env : (n_frames > 0 ? resident_cu_count() / n_frames : 0);
@@ -234,6 +236,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
             R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb;
             while (R.n_bands > RES_MAX_BANDS) { R.band_wb *= 2; R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb; }
             R.window = win_env;
+            R.chunk_log2 = chunk == 128 ? 7 : 6;
             R.cap_tiles = (unsigned)(N / 8 + 1024);
             if (std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES")) {   // (tests shrink it to see the planner give up)
                 const int ct = std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES"));

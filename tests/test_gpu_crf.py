@@ -237,21 +237,21 @@ def test_queue_splat_is_bit_exact_too(gpu_ctx_factory, oracle, band):
         assert np.array_equal(out["labels"][i].ravel(), lab), i
 
 
-@pytest.mark.parametrize("B,band,ring,window", [(2, 1, 8, 1), (8, 8, 8, 1), (16, 4, 16, 0), (5, 32, 8, -1), (3, 2, 8, 2)])
-def test_resident_band_splat_is_bit_exact(gpu_ctx_factory, oracle, B, band, ring, window):
+@pytest.mark.parametrize("B,band,chunk,window", [(2, 1, 64, 1), (8, 8, 128, 1), (16, 4, 64, 0), (5, 32, 128, -1), (3, 2, 128, 2), (4, 16, 64, -1)])
+def test_resident_band_splat_is_bit_exact(gpu_ctx_factory, oracle, B, band, chunk, window):
     """The resident band schedule of the mean-field splat (default for chunks of more than 16
     frames, forced here for 8 + 1): a frame's vertices dealt to B blocks, each walking its vertices band by band
     through a precomputed tile list (64-entry chunks packed seven to a tile by the wrap-around rule), the running sums
     parked in LDS and swapped when a slot changes its vertex.  Every chain is still summed in ascending point order
-    inside one block, so nothing may change -- for any number of blocks, band size, ring depth and pacing window
-    (-1 = no pacing)."""
+    inside one block, so nothing may change -- for any number of blocks, band size, tile height (64 / 128 entries per
+    slot) and pacing window (-1 = no pacing)."""
     blob = synthetic.make_forest_bytes(seed=24, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
     forest = oracle.Forest(blob)
     W, H = 320, 240
     rgb, depth = synthetic.make_batch(9, W, H, holes=True, start=2)
     calib = synthetic.make_calib(W, H)
     env = {"RVSEG_SPLAT_RESIDENT": "2", "RVSEG_SPLAT_RESIDENT_B": str(B), "RVSEG_SPLAT_RESIDENT_BAND": str(band),
-           "RVSEG_SPLAT_RESIDENT_RING": str(ring), "RVSEG_SPLAT_RESIDENT_WINDOW": str(window)}
+           "RVSEG_SPLAT_RESIDENT_CHUNK": str(chunk), "RVSEG_SPLAT_RESIDENT_WINDOW": str(window)}
     os.environ.update(env)
     try:
         ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=3, label_mode=1, unknown_label=[8], max_batch=16)
