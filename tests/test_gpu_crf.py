@@ -318,3 +318,34 @@ def test_resident_band_splat_two_layers_and_fine_lattices(gpu_ctx_factory, oracl
         post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[7, 8])
         assert np.array_equal(out["marginals"][i], marg), i
         assert np.array_equal(out["labels"][i].ravel(), lab), i
+
+
+@pytest.mark.parametrize("n_frames", [17, 20, 43])
+def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_factory, oracle, n_frames):
+    """No environment switches: chunks of more than 16 frames take the resident schedule by themselves, with
+    B = CUs / frames blocks per frame (12, 12, 5 here) and frame counts that leave the XCD groups uneven."""
+    blob = synthetic.make_forest_bytes(seed=24, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
+    forest = oracle.Forest(blob)
+    W, H = 160, 120
+    rgb, depth = synthetic.make_batch(n_frames, W, H, holes=True, start=3)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, dcrf_iterations=2)
+    ctx = gpu_ctx_factory(multi_layer=0, use_dense_crf=1, label_mode=1, unknown_label=[8], max_batch=64, **kw)
+    ctx.forest_load(blob)
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    N = W * H
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_marg = torch.zeros((n_frames, 9 * N), dtype=torch.float32, device=dev)
+    d_lab = torch.full((n_frames, N), -99, dtype=torch.int8, device=dev)
+    ctx.segment_frames_device(n_frames, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream)
+    assert ctx.poll_status(wait=True) == 0
+    torch.cuda.synchronize(dev)
+    marg = d_marg.cpu().numpy(); lab = d_lab.cpu().numpy()
+    p = oracle.default_params(**kw)
+    for i in range(n_frames):
+        _, wm, wl = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
+        assert np.array_equal(marg[i], wm), i
+        assert np.array_equal(lab[i], wl), i
