@@ -17,6 +17,7 @@
 //     index.  To stay bit-exact the splat is a GATHER: entries are stably sorted by vertex and each
 //     (vertex, class) chain adds its contributions in ascending point order.  No float atomics.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -1745,7 +1746,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
     for (unsigned e = threadIdx.x; e < n_own * CC; e += 512) values[((size_t)f0 + verts[e / CC]) * C + e % CC] = accs[e];
 }
 
-static unsigned g_resident_tag = 0;
+static std::atomic<unsigned> g_resident_tag{0};   // launch tags of the pacing words (any two concurrent launches just need different ones)
 
 static size_t resident_lds_bytes(int CC, int TH) {
     return ((size_t)2 * 7 * CC * (TH + 4) + (size_t)(RES_MAX_OWNV + 1) * CC) * sizeof(float) + 2 * 64 * 8 * sizeof(unsigned);
@@ -1784,7 +1785,7 @@ template <int CC>
 static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
     const unsigned NG = (unsigned)L.n_groups;
     const unsigned rounds = ((unsigned)L.n_frames + NG - 1u) / NG;
-    g_resident_tag = (g_resident_tag % 0x7FFFu) + 1u;
+    const unsigned tag = (g_resident_tag.fetch_add(1u) % 0x7FFFu) + 1u;
     const ValueView sv{const_cast<float*>(src), (size_t)L.N * (unsigned)CC, 0};
     // items of the list-major walk, should the planner have given up (splat_group_launch_g's grid)
     const unsigned nfg = ((unsigned)L.n_frames + NG - 1u) / NG;
@@ -1792,9 +1793,9 @@ static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
     const unsigned n_items = nfg * (unsigned)((max_mf + 6) / 7) * NG;
     const dim3 grid(rounds * (unsigned)R.B * NG), block(512);
     if (R.chunk_log2 == 7) {
-        if (resident_setup<CC, 128>()) splat_resident_kernel<CC, 8, 4, 128><<<grid, block, resident_lds_bytes(CC, 128), s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+        if (resident_setup<CC, 128>()) splat_resident_kernel<CC, 8, 4, 128><<<grid, block, resident_lds_bytes(CC, 128), s>>>(L, R, sv, values, tag, slot, n_items);
     } else {
-        if (resident_setup<CC, 64>()) splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, g_resident_tag, slot, n_items);
+        if (resident_setup<CC, 64>()) splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, tag, slot, n_items);
     }
 }
 
