@@ -219,7 +219,10 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         const int b_env = std::getenv("RVSEG_SPLAT_RESIDENT_B") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_B")) : 0;
         const int band_env = std::getenv("RVSEG_SPLAT_RESIDENT_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_BAND")) : 16;
         const int win_env = std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW")) : -1;   // measured: pacing costs more than its locality saves (the kernel is issue bound)
-        const int min_frames = res_env > 1 ? 1 : 17;   // 2 = also for few frames (experiments)
+        // Worth it where the list-major walk is bound by the bytes it re-reads: measured equal at 32 frames of 640x480
+        // (9.8 M points per chunk), 12 % faster at 64, 10 % faster at 16 frames of 1280x960 (19.7 M); slower on a single
+        // frame or cloud, whose longest chain sets the time (RVSEG_SPLAT_RESIDENT=2: always, for tests)
+        const bool big_enough = res_env > 1 || (n_frames >= 2 && (long long)n_frames * N >= 12000000ll);
         const int chunk_env = std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK")) : 128;
         const int chunk = chunk_env == 64 ? 64 : 128;
         const int capacity = resident_block_capacity(chunk);
@@ -228,7 +231,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         int B = b_env > 0 ? b_env : (n_frames > 0 ? resident_cu_count() / n_frames : 0);
         if (b_env <= 0) B = B < 2 ? 2 : (B > 12 ? 12 : B);
         B = B > RES_MAXB ? RES_MAXB : B;
-        if (res_env && !b.queue_on && L.bh && d == 6 && n_frames >= min_frames && B >= 2 && (long long)n_frames * B <= capacity &&
+        if (res_env && !b.queue_on && L.bh && d == 6 && big_enough && B >= 2 && (long long)n_frames * B <= capacity &&
             7ll * N < (1ll << 24) && (long long)L.wbpf <= 32ll * RES_MAX_BANDS) {   // (bands stay under 64 wave-blocks: chunk counts fit 8 bits)
             SplatResidentDev& R = b.resident;
             R.B = B;

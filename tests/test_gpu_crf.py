@@ -322,8 +322,9 @@ def test_resident_band_splat_two_layers_and_fine_lattices(gpu_ctx_factory, oracl
 
 @pytest.mark.parametrize("n_frames", [17, 20, 43])
 def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_factory, oracle, n_frames):
-    """No environment switches: chunks of more than 16 frames take the resident schedule by themselves, with
-    B = CUs / frames blocks per frame (12, 12, 5 here) and frame counts that leave the XCD groups uneven."""
+    """The resident schedule with its own choice of B = CUs / frames blocks per frame (12, 12, 5 here) and frame counts
+    that leave the XCD groups uneven.  (Forced: by itself the library takes this schedule from 12 M points per chunk,
+    where it is faster than the list-major walk -- 64 frames of 640x480 in test_gpu_batch64.py.)"""
     blob = synthetic.make_forest_bytes(seed=24, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
     forest = oracle.Forest(blob)
     W, H = 160, 120
@@ -339,8 +340,12 @@ def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_facto
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     d_marg = torch.zeros((n_frames, 9 * N), dtype=torch.float32, device=dev)
     d_lab = torch.full((n_frames, N), -99, dtype=torch.int8, device=dev)
-    ctx.segment_frames_device(n_frames, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
-                              torch.cuda.current_stream(dev).cuda_stream)
+    os.environ["RVSEG_SPLAT_RESIDENT"] = "2"
+    try:
+        ctx.segment_frames_device(n_frames, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream)
+    finally:
+        del os.environ["RVSEG_SPLAT_RESIDENT"]
     assert ctx.poll_status(wait=True) == 0
     torch.cuda.synchronize(dev)
     marg = d_marg.cpu().numpy(); lab = d_lab.cpu().numpy()
