@@ -61,6 +61,43 @@ __global__ void __launch_bounds__(256) cal_gather36(const float* __restrict__ ro
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// ---- streaming 36-byte rows, one row per lane (lane i reads bytes [36 i, 36 i + 36) as x4 + x4 + x1): the access shape
+//      of the row-per-thread streaming kernels (mf_update, softmax_unary, upsample) ---------------------------------
+__global__ void __launch_bounds__(256) cal_rows36_per_lane(const float* __restrict__ rows, size_t n_rows, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (size_t)gridDim.x * 256) {
+        const float* p = rows + i * 9;
+        const f32x4_u a = *reinterpret_cast<const f32x4_u*>(p);
+        const f32x4_u b = *reinterpret_cast<const f32x4_u*>(p + 4);
+        const float c = p[8];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c;
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+// the same rows fetched as 16 bytes per lane, coalesced (a wave's 64 rows are 2304 contiguous bytes = 144 x 16 B: three
+// wave-loads of which the third is three-quarters empty), parked in LDS and read back row-wise by the lane that owns them
+__global__ void __launch_bounds__(256) cal_rows36_via_lds(const float* __restrict__ rows, size_t n_rows, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * 9 + 12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    float* st = stage[wave];
+    for (size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 64; r0 + 64 <= n_rows; r0 += (size_t)gridDim.x * 256) {
+        const float4* src = reinterpret_cast<const float4*>(rows + r0 * 9);   // 36 * 64 * k bytes: 16-byte aligned when r0 is a multiple of 4
+        const float4 v0 = src[lane], v1 = src[64 + lane];
+        float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 16) v2 = src[128 + lane];
+        reinterpret_cast<float4*>(st)[lane] = v0;
+        reinterpret_cast<float4*>(st)[64 + lane] = v1;
+        if (lane < 16) reinterpret_cast<float4*>(st)[128 + lane] = v2;
+        __builtin_amdgcn_wave_barrier();
+        const float* p = st + lane * 9;   // stride 9 words: conflict-free
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc += p[k];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // ---- K bytes per lane from the start of a random 128-byte-aligned line (granularity probe) ----------
 template <int K>
 __global__ void __launch_bounds__(256) cal_gather_line(const float* __restrict__ base, const unsigned* __restrict__ idx, size_t n,
@@ -127,6 +164,10 @@ int main() {
         t.start(); cal_stream16<<<grid, block>>>(reinterpret_cast<const float4*>(buf), BYTES / 16, sink); report("cal_stream16", (double)BYTES, (double)BYTES, (double)BYTES, t.stop());
         t.start(); cal_stream8<<<grid, block>>>(reinterpret_cast<const uint2*>(buf), BYTES / 8, sink); report("cal_stream8", (double)BYTES, (double)BYTES, (double)BYTES, t.stop());
         t.start(); cal_stream4<<<grid, block>>>(reinterpret_cast<const unsigned*>(buf), BYTES / 4, sink); report("cal_stream4", (double)BYTES, (double)BYTES, (double)BYTES, t.stop());
+    }
+    for (int rep = 0; rep < 2; rep++) {
+        t.start(); cal_rows36_per_lane<<<grid, block>>>(buf, n_rows, sink); report("cal_rows36_per_lane", 36.0 * n_rows, (double)BYTES, (double)BYTES, t.stop());
+        t.start(); cal_rows36_via_lds<<<grid, block>>>(buf, n_rows, sink); report("cal_rows36_via_lds", 36.0 * n_rows, (double)BYTES, (double)BYTES, t.stop());
     }
     // (a) every lane its own random row: no coalescing at all
     for (size_t i = 0; i < NG; i++) idx[i] = (unsigned)(rng() % n_rows);
