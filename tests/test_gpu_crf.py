@@ -354,3 +354,45 @@ def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_facto
         _, wm, wl = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
         assert np.array_equal(marg[i], wm), i
         assert np.array_equal(lab[i], wl), i
+
+
+def test_config5_chunk_resident_schedule_equals_list_major_walk(gpu_ctx_factory, oracle):
+    """BASELINE configs[4] as bench.py runs it on one GPU: a chunk of 16 frames of 1280x960 with two label layers and 10
+    CRF iterations (19.7 M points: the library takes the resident band schedule by itself, one launch per layer on two
+    streams).  The same chunk with RVSEG_SPLAT_RESIDENT=0 walks the lists the list-major way; both orders of work sum
+    every chain in ascending point order, so marginals and labels have to be identical to the bit -- and frame 5 is
+    checked against the CPU oracle as well."""
+    torch = pytest.importorskip("torch")
+    W, H, n = 1280, 960, 16
+    N = W * H
+    blob = synthetic.make_forest_bytes(seed=23, n_trees=4, leaves_per_tree=512, max_depth=14)
+    rgb, depth = synthetic.make_batch(n, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    kw = dict(width=W, height=H, multi_layer=1, use_dense_crf=1, dcrf_iterations=10, label_mode=1, unknown_label=[7, 8], max_batch=n)
+    results = []
+    for resident in ("1", "0"):
+        ctx = gpu_ctx_factory(**kw)
+        ctx.forest_load(blob)
+        d_marg = torch.zeros((n, 17 * N), dtype=torch.float32, device=dev)
+        d_lab = torch.full((n, 2 * N), -99, dtype=torch.int8, device=dev)
+        os.environ["RVSEG_SPLAT_RESIDENT"] = resident
+        try:
+            ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
+                                      torch.cuda.current_stream(dev).cuda_stream)
+            assert ctx.poll_status(wait=True) == 0
+        finally:
+            del os.environ["RVSEG_SPLAT_RESIDENT"]
+        torch.cuda.synchronize(dev)
+        results.append((d_marg, d_lab))
+        ctx.close()
+    assert torch.equal(results[0][0], results[1][0])
+    assert torch.equal(results[0][1], results[1][1])
+    assert (results[0][1] != -99).all()
+    forest = oracle.Forest(blob)
+    p = oracle.default_params(width=W, height=H, dcrf_iterations=10)
+    _, marg, lab = oracle.segment_frame(p, forest, 1, rgb[5], depth[5], calib, label_mode=1, unknown=[7, 8])
+    assert np.array_equal(results[0][0][5].cpu().numpy(), marg)
+    assert np.array_equal(results[0][1][5].cpu().numpy(), lab)
