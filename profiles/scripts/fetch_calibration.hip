@@ -61,6 +61,18 @@ __global__ void __launch_bounds__(256) cal_gather36(const float* __restrict__ ro
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// ---- the same gather from rows padded to 48 bytes (12 floats, 16-byte aligned): three aligned x4 per row ----------
+__global__ void __launch_bounds__(256) cal_gather48(const float* __restrict__ rows, const unsigned* __restrict__ idx, size_t n,
+                                                    float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4* p = reinterpret_cast<const float4*>(rows + (size_t)idx[i] * 12);
+        const float4 a = p[0], b = p[1], c = p[2];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x;
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // ---- streaming 36-byte rows, one row per lane (lane i reads bytes [36 i, 36 i + 36) as x4 + x4 + x1): the access shape
 //      of the row-per-thread streaming kernels (mf_update, softmax_unary, upsample) ---------------------------------
 __global__ void __launch_bounds__(256) cal_rows36_per_lane(const float* __restrict__ rows, size_t n_rows, float* __restrict__ sink) {
@@ -182,6 +194,16 @@ int main() {
         double b64, b128; granule_bytes(idx, b64, b128);
         CK(hipMemcpy(d_idx, idx.data(), NG * 4, hipMemcpyHostToDevice));
         for (int rep = 0; rep < 2; rep++) { t.start(); cal_gather36<<<grid, block>>>(buf, d_idx, NG, sink); report("cal_gather36_runs16", 36.0 * NG, b64, b128, t.stop()); }
+    }
+    {   // (b') the same runs of 16 rows from 48-byte rows (indices scaled down so that they stay inside the buffer)
+        std::vector<unsigned> idx48(NG);
+        const size_t n_rows48 = BYTES / 48;
+        for (size_t i = 0; i < NG; i += 16) { const unsigned r0 = (unsigned)(rng() % (n_rows48 - 16)); for (int k = 0; k < 16; k++) idx48[i + k] = r0 + k; }
+        CK(hipMemcpy(d_idx, idx48.data(), NG * 4, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) { t.start(); cal_gather48<<<grid, block>>>(buf, d_idx, NG, sink); report("cal_gather48_runs16", 36.0 * NG, 48.0 * NG, 48.0 * NG, t.stop()); }
+        for (size_t i = 0; i < NG; i += 16) { const unsigned r0 = (unsigned)(rng() % (n_rows - 16)); for (int k = 0; k < 16; k++) idx[i + k] = r0 + k; }
+        CK(hipMemcpy(d_idx, idx.data(), NG * 4, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) { t.start(); cal_gather36<<<grid, block>>>(buf, d_idx, NG, sink); report("cal_gather36_runs16_again", 36.0 * NG, 0, 0, t.stop()); }
     }
     // (c) whole tiles of 64 consecutive rows
     for (size_t i = 0; i < NG; i += 64) { const unsigned r0 = (unsigned)(rng() % (n_rows - 64)); for (int k = 0; k < 64; k++) idx[i + k] = r0 + k; }
