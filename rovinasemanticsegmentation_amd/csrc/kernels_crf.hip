@@ -955,7 +955,7 @@ static int splat_gv_choice(const LatticeDev& L) {
 }
 
 template <int CC>
-static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s);
+static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s);
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
                   const SplatQueueDev* queue, const SplatResidentDev* resident, int slot) {
@@ -966,9 +966,9 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
     if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8) && resident) {
         // resident band schedule (the kernel walks the lists the list-major way itself should the planner have given up)
-        if (C == 9) splat_resident_launch<9>(L, *resident, src.base, values, slot, s);
-        else splat_resident_launch<8>(L, *resident, src.base, values, slot, s);
-        return;
+        const bool ran = C == 9 ? splat_resident_launch<9>(L, *resident, src.base, values, slot, s)
+                                : splat_resident_launch<8>(L, *resident, src.base, values, slot, s);
+        if (ran) return;
     }
     if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
         // experimental band-major schedule; the regular launch below stands by and returns at once when the queue is valid
@@ -1781,8 +1781,9 @@ int resident_block_capacity(int chunk) {
     return cap[which];
 }
 
+// false: the kernel could not be set up (its dynamic LDS was refused): the caller walks the lists the list-major way
 template <int CC>
-static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
+static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
     const unsigned NG = (unsigned)L.n_groups;
     const unsigned rounds = ((unsigned)L.n_frames + NG - 1u) / NG;
     const unsigned tag = (g_resident_tag.fetch_add(1u) % 0x7FFFu) + 1u;
@@ -1793,10 +1794,13 @@ static void splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
     const unsigned n_items = nfg * (unsigned)((max_mf + 6) / 7) * NG;
     const dim3 grid(rounds * (unsigned)R.B * NG), block(512);
     if (R.chunk_log2 == 7) {
-        if (resident_setup<CC, 128>()) splat_resident_kernel<CC, 8, 4, 128><<<grid, block, resident_lds_bytes(CC, 128), s>>>(L, R, sv, values, tag, slot, n_items);
+        if (!resident_setup<CC, 128>()) return false;
+        splat_resident_kernel<CC, 8, 4, 128><<<grid, block, resident_lds_bytes(CC, 128), s>>>(L, R, sv, values, tag, slot, n_items);
     } else {
-        if (resident_setup<CC, 64>()) splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, tag, slot, n_items);
+        if (!resident_setup<CC, 64>()) return false;
+        splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, tag, slot, n_items);
     }
+    return true;
 }
 
 int csr_pix_per_block() { return CS_PIX; }
