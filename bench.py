@@ -4,7 +4,12 @@
 A "step" is one pass of the hot path over one batch of 64 synthetic 640x480 key frames
 (BASELINE.json configs[2], the HBM-roofline run; configs[1] -- a single frame -- is the same call
 with n = 1 and is reported as `latency_ms_single_frame`).  Inputs are resident in HBM before the
-timed region; every step writes CRF marginals and labels to HBM.
+timed region; every step writes CRF marginals and labels to HBM.  The frames have invalid-depth holes
+(like every parity test) and the steps alternate between two different input sets.
+
+`--config 3` times BASELINE.json configs[3] instead: every rank owns 32 key frames of the local map
+(256 frames over 8 GPUs) and every step ends with the label gather to the fusion rank (RCCL; at N = 1
+through the C ABI's own communicator of world size 1).
 
 Multi-GPU: one process per GPU, frames shard across ranks with no data-path
 collective except the final local-map label gather to rank 0 over RCCL, i.e. weak scaling.  Two ways
@@ -70,6 +75,10 @@ def _latest(pattern):
     return files[-1] if files else None
 
 
+class PmcNameError(RuntimeError):
+    pass
+
+
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the committed PMC summary.  FETCH_SIZE and
     WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte fabric request as 64 bytes
@@ -93,7 +102,9 @@ def pmc_traffic(stage):
         if r:
             break
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
-        return None
+        # a renamed kernel (new template arguments ...) must not turn `traffic` into a silent null
+        raise PmcNameError("bench.py: no PMC record for stage %r (kernel %s) in %s -- re-run profiles/scripts/pmc.sh "
+                           "and commit the summary, or fix STAGE_KERNEL" % (stage, " | ".join(names), os.path.basename(f)))
     factor = 2.0
     cal = _latest("*_fetch_calibration.json")
     if cal:
@@ -108,7 +119,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_STEP, help="key frames per step and GPU")
+    ap.add_argument("--frames", type=int, default=None, help="key frames per step and GPU (default 64; 32 with --config 3)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
+                    help="BASELINE.json configs[k]: 2 = batch of 64 frames per GPU (default, the headline), 3 = local map of "
+                         "256 key frames sharded over 8 GPUs (32 per rank) + label gather to the fusion rank every step")
+    ap.add_argument("--no-overlap", action="store_true", help="every kernel alone on the GPU (profiling: no side streams)")
+    ap.add_argument("--no-holes", action="store_true", help="frames without invalid-depth holes (round 1/2 inputs)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
@@ -119,7 +135,10 @@ def parse():
     ap.add_argument("--rehearsal", action="store_true",
                     help="CPU rehearsal of the multi-rank protocol (gloo, no GPU, no hot path): launcher, sharding, "
                          "gather, barriers, max-over-ranks timing")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 32 if args.config == 3 else FRAMES_PER_STEP
+    return args
 
 
 # ------------------------------------------------------------------------------------------------
@@ -150,10 +169,32 @@ def launch_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all ranks: when one exits with an error (or the whole run takes too long) the others would sit in
+    # init_process_group / barrier for ever -- end them and report that rank's code
+    deadline = time.time() + float(os.environ.get("RVSEG_BENCH_LAUNCH_TIMEOUT_S", "1500"))
     rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.time() > deadline:
+            sys.stderr.write("bench.py: ranks still running after the launch timeout; terminating them\n")
+            rc = 124
+            break
+        time.sleep(0.2)
     for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+        if p.poll() is None:
+            p.terminate()
+    t_end = time.time() + 10
+    for p in procs:
+        try:
+            p.wait(max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
     return rc
 
 
@@ -287,29 +328,42 @@ def main():
     N = W * H
     blob = synthetic.make_forest_bytes(seed=7, n_trees=4, leaves_per_tree=1 << 14, max_depth=30,
                                        single_classes=C_CLASSES, layer_classes=(8, 9))
-    # each rank owns different frames of the local map
-    rgb_h, depth_h = synthetic.make_batch(n, W, H, holes=False, start=rank * n)
+    # each rank owns different frames of the local map; the steps alternate between two input sets (frames
+    # [rank * n, rank * n + n) of map 0 and of map 1), both resident in HBM before the timed region
+    N_SETS = 2
+    holes = not args.no_holes
+    sets_h = [synthetic.make_batch(n, W, H, holes=holes, start=(k * world + rank) * n) for k in range(N_SETS)]
+    rgb_h, depth_h = sets_h[0]
     calib = synthetic.make_calib(W, H)
-    d_rgb = torch.from_numpy(rgb_h).to(dev)
-    d_depth = torch.from_numpy(depth_h.view(np.int16)).to(dev)
+    d_sets = [(torch.from_numpy(r).to(dev), torch.from_numpy(d.view(np.int16)).to(dev)) for r, d in sets_h]
+    d_rgb, d_depth = d_sets[0]
     d_marg = torch.empty((n, C_CLASSES * N), dtype=torch.float32, device=dev)
     d_labels = torch.empty((n, N), dtype=torch.int8, device=dev)
     # the local-map label gather: receive buffers exist once, before the timed region
     gatherer = FrameGatherer(n * world, (N,), torch.int8, dev if backend == "nccl" else "cpu") if world > 1 else None
+    d_fused = torch.empty((n, N), dtype=torch.int8, device=dev) if (world == 1 and args.config == 3) else None
 
     ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=CRF_ITERS, label_mode=rv.capi.LABEL_CRF,
                      unknown_label=[8], max_batch=n, device=dev.index or 0,
                      # the Segmenter kernel (xyz*0.5, rgb*4) yields ~300 lattice vertices per frame;
                      # 2^12 slots per frame keep the per-vertex launches small (overflow is detected)
-                     lattice_capacity_log2=int(os.environ.get("RVSEG_BENCH_CAPACITY_LOG2", "12")))
+                     lattice_capacity_log2=int(os.environ.get("RVSEG_BENCH_CAPACITY_LOG2", "12")),
+                     schedule=dict(overlap_build=0, overlap_layers=0) if args.no_overlap else None)
     ctx.forest_load(blob)
     stream = torch.cuda.current_stream(dev)
+    if d_fused is not None:   # configs[3] on one GPU: the C ABI's RCCL gather, world size 1
+        ctx.comm_init(0, 1, rv.Context.comm_unique_id())
+    steps_done = [0]
 
     def step():
-        ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(),
+        rgb_d, depth_d = d_sets[steps_done[0] % N_SETS]
+        steps_done[0] += 1
+        ctx.segment_frames_device(n, rgb_d.data_ptr(), depth_d.data_ptr(), calib, 0, d_marg.data_ptr(),
                                   d_labels.data_ptr(), stream.cuda_stream)
         if world > 1:  # local-map label fusion: one gather to the fusion rank over xGMI
             gatherer.gather(d_labels if backend == "nccl" else d_labels.cpu())
+        elif d_fused is not None:
+            ctx.gather_frames(d_labels.data_ptr(), d_labels.numel(), d_fused.data_ptr(), 0, stream.cuda_stream)
 
     def barrier():
         if world > 1:
@@ -329,6 +383,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     async_status = ctx.poll_status(wait=True)   # hash overflow of the last step would show here
+    schedule = ctx.last_schedule()
+    last_set = (steps_done[0] - 1) % N_SETS
 
     # per-stage durations of the LAST step, from HIP events recorded on the launch stream
     stages = ctx.last_timing()
@@ -341,7 +397,12 @@ def main():
     verified = None
     if rank == 0 and not args.no_verify:
         vf = 9 % n
-        verified = verify_frame(blob, rgb_h, depth_h, calib, d_marg[vf].cpu().numpy(), d_labels[vf].cpu().numpy(), vf)
+        verified = verify_frame(blob, sets_h[last_set][0], sets_h[last_set][1], calib, d_marg[vf].cpu().numpy(),
+                                d_labels[vf].cpu().numpy(), vf)
+        verified["input_set"] = last_set
+        if d_fused is not None:
+            verified["gather_ok"] = bool(torch.equal(d_fused, d_labels))
+            verified["ok"] = verified["ok"] and verified["gather_ok"]
 
     # single-frame latency (configs[1]) -- outside the timed region
     lat = None
@@ -382,7 +443,8 @@ def main():
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic(dom) if n == FRAMES_PER_STEP else None,
+                    # PMC counters of this very command (profiles/scripts/pmc.sh); only the headline shape has them
+                    "traffic": pmc_traffic(dom) if (n == FRAMES_PER_STEP and args.config == 2 and not args.no_overlap) else None,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": k,
                     "algorithmic_bytes_per_launch": bytes_per_launch}
         out = {
@@ -390,10 +452,17 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 640x480 RGB-D key frames per GPU, 4-tree forest "
-                                   "(2^14 leaves/tree, D=366, C=9), RF + 5-iter DenseCRF (d=6, Potts w=10), "
-                                   "marginals + labels written to HBM" % n,
-                       "frames_per_step_per_gpu": n, "label_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1 else "none"},
+            "config": {"workload": ("BASELINE configs[3]: local map of %d key frames sharded over %d GPU(s), %d per rank, "
+                                    % (n * world, world, n) if args.config == 3 else "BASELINE configs[2]: ") +
+                                   "batch of %d synthetic 640x480 RGB-D key frames per GPU (10 %% invalid-depth holes: %s; "
+                                   "%d input sets in rotation), 4-tree forest (2^14 leaves/tree, D=366, C=9), RF + 5-iter "
+                                   "DenseCRF (d=6, Potts w=10), marginals + labels written to HBM"
+                                   % (n, "yes" if holes else "no", N_SETS),
+                       "baseline_config": args.config,
+                       "frames_per_step_per_gpu": n,
+                       "label_gather": ("%s gather to rank 0" % ("rccl" if backend == "nccl" else backend)) if world > 1
+                                       else ("rccl gather, world size 1 (C ABI)" if d_fused is not None else "none")},
+            "schedule": schedule,
             "roofline": roof,
             "verified": (verified["ok"] if verified else None), "verification": verified,
             "async_status": "ok" if async_status == rv.capi.OK else str(async_status),

@@ -304,6 +304,43 @@ void rvseg_comm_destroy(rvseg_ctx *ctx);
 rvseg_status rvseg_gather_frames(rvseg_ctx *ctx, const void *d_local, size_t bytes_per_rank, void *d_recv,
                                  int32_t root, void *hip_stream);
 
+/* ---- launch schedules.  The library picks the schedule of the ordered splat (the dominant kernel) and the stream
+ *      overlaps from the shape of the work; this block overrides those choices for tests, profiling and tuning.
+ *      Nothing on the call path reads the environment.  The reference has no counterpart (single thread). */
+typedef struct rvseg_schedule {
+    int32_t splat;               /* 0 = chosen from the chunk (default), 1 = list-major walk, 2 = resident bands
+                                    (forced wherever its tables fit)                                              */
+    int32_t resident_blocks;     /* resident bands: blocks per frame, 0 = CUs / frames (2..12)                    */
+    int32_t resident_band;       /* wave-blocks of 256 points per band (default 16 = 4096 points)                 */
+    int32_t resident_chunk;      /* entries per slot and tile: 64 or 128 (default 128)                            */
+    int32_t resident_window;     /* pacing window in bands, -1 = no pacing (default)                              */
+    int32_t resident_cap_tiles;  /* tile table per frame, 0 = N / 8 + 1024 (tests shrink it: planner fall-back)   */
+    int32_t group_vertices;      /* list-major walk, C = 8 / 9: vertices per block, 0 = by the chunk, 6 or 7      */
+    int32_t overlap_build;       /* 1 (default): lattice build on a side stream beside features + forest          */
+    int32_t overlap_layers;      /* 1 (default): the label layers' mean fields on two streams                     */
+    int32_t build_priority_high; /* 0 (default): the build stream has the lowest priority                         */
+    int32_t trace;               /* 1: per-block trace of the resident splat (debugging); 2: + synchronous stderr marks */
+} rvseg_schedule;
+void rvseg_schedule_default(rvseg_schedule *s);
+/* Applies to every later call on ctx (buffers of a schedule are allocated on first use). */
+rvseg_status rvseg_set_schedule(rvseg_ctx *ctx, const rvseg_schedule *s);
+
+/* What the last lattice build + mean field on this context ran with.  `planner_fallback` and `vertices` come from
+ * the device with the build's status: they are valid once rvseg_poll_status(ctx, 1) has returned (host entry points:
+ * on return), -1 before.  A planner fall-back is not an error -- the same grid walks the lists the list-major way,
+ * results are identical -- but it is slower, so it is reported here instead of staying silent. */
+typedef struct rvseg_schedule_info {
+    int32_t splat;               /* 0 = no lattice built yet, 1 = list-major walk, 2 = resident bands             */
+    int32_t planner_fallback;    /* resident bands planned, but the planner gave up on this many frames           */
+    int32_t csr_path;            /* 1 = counting sort, 2 = radix sort                                             */
+    int32_t n_frames;            /* frames (1 for a cloud) and points per frame of that lattice                   */
+    int32_t points_per_frame;
+    int32_t vertices;            /* lattice vertices over all frames                                              */
+    int32_t resident_blocks, resident_band, resident_chunk;   /* the resident schedule's shape (0 when not used)  */
+    int32_t capacity_log2;       /* hash slots per frame                                                          */
+} rvseg_schedule_info;
+rvseg_status rvseg_last_schedule(rvseg_ctx *ctx, rvseg_schedule_info *out);
+
 /* ---- timing of the last segment_frames / crf_infer call, measured with HIP events on the
  *      stream the kernels ran on.  names_out receives a ';'-separated list of stage names,
  *      ms_out up to max_stages durations.  Returns the number of stages. */

@@ -1,9 +1,8 @@
-"""Per-block timing of the resident band splat (RVSEG_SPLAT_RESIDENT_TRACE=1): run on the GPU box.
+"""Per-block timing of the resident band splat (rvseg_schedule.trace = 1): run on the GPU box.
 Prints, for the last splat launch of a 64-frame chunk: span of the launch, and per block of one frame its tiles,
 run time, time per tile and time spent waiting for the pace."""
 import ctypes as C, numpy as np, torch, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-os.environ["RVSEG_SPLAT_RESIDENT_TRACE"] = "1"
 import rovinasemanticsegmentation_amd as rv
 from rovinasemanticsegmentation_amd import synthetic
 W, H, N, n = 640, 480, 640 * 480, 64
@@ -12,7 +11,7 @@ blob = synthetic.make_forest_bytes(seed=7, n_trees=4, leaves_per_tree=1 << 14, m
 rgb, depth = synthetic.make_batch(n); calib = synthetic.make_calib()
 d_rgb = torch.from_numpy(rgb).to(dev); d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
 d_marg = torch.empty((n, 9 * N), dtype=torch.float32, device=dev); d_lab = torch.empty((n, N), dtype=torch.int8, device=dev)
-ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=5, label_mode=1, unknown_label=[8], max_batch=n, lattice_capacity_log2=12)
+ctx = rv.Context(multi_layer=0, use_dense_crf=1, dcrf_iterations=5, label_mode=1, unknown_label=[8], max_batch=n, lattice_capacity_log2=12, schedule=dict(trace=1))
 ctx.forest_load(blob)
 s = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(2):

@@ -1,12 +1,12 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-export RVSEG_NO_OVERLAP=1
+# every kernel alone on the GPU: bench.py --no-overlap (rvseg_schedule.overlap_build / overlap_layers = 0)
 rm -rf $R/gpurun_out/pmc_fe; mkdir -p $R/gpurun_out/pmc_fe
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" "TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_fe/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --no-latency --no-verify --extras none > $R/gpurun_out/pmc_fe/log$i.txt 2>&1
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_fe/p$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-overlap --no-cpu --no-latency --no-verify --extras none > $R/gpurun_out/pmc_fe/log$i.txt 2>&1
   echo "pass $i rc=$?"
 done
 python3 - <<'PY'

@@ -29,6 +29,7 @@ SYMBOLS = [
     "rvseg_crf_features_gaussian", "rvseg_crf_features_bilateral",
     "rvseg_train_params_default", "rvseg_forest_train",
     "rvseg_comm_unique_id", "rvseg_comm_init", "rvseg_comm_destroy", "rvseg_gather_frames",
+    "rvseg_schedule_default", "rvseg_set_schedule", "rvseg_last_schedule",
 ]
 
 
@@ -55,6 +56,21 @@ class RvsegTrainParams(C.Structure):
         ("min_child_split_examples", C.c_int32), ("num_features", C.c_int32), ("use_bootstrap", C.c_int32),
         ("smoothing", C.c_float), ("seed", C.c_uint64),
     ]
+
+
+class RvsegSchedule(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "splat", "resident_blocks", "resident_band", "resident_chunk", "resident_window", "resident_cap_tiles",
+        "group_vertices", "overlap_build", "overlap_layers", "build_priority_high", "trace")]
+
+
+class RvsegScheduleInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "splat", "planner_fallback", "csr_path", "n_frames", "points_per_frame", "vertices", "resident_blocks",
+        "resident_band", "resident_chunk", "capacity_log2")]
+
+
+SPLAT_NAMES = {0: "none", 1: "list-major", 2: "resident"}
 
 
 class RvsegError(RuntimeError):
@@ -125,6 +141,10 @@ def lib():
     L.rvseg_gather_frames.argtypes = [vp, vp, C.c_size_t, vp, i32, vp]
     L.rvseg_crf_features_gaussian.argtypes = [i32, i32, f32, f32, vp]
     L.rvseg_crf_features_bilateral.argtypes = [i32, i32, f32, f32, f32, f32, f32, vp, vp]
+    L.rvseg_schedule_default.argtypes = [C.POINTER(RvsegSchedule)]
+    L.rvseg_schedule_default.restype = None
+    L.rvseg_set_schedule.argtypes = [vp, C.POINTER(RvsegSchedule)]
+    L.rvseg_last_schedule.argtypes = [vp, C.POINTER(RvsegScheduleInfo)]
     for name in SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library does not export it
     _lib = L

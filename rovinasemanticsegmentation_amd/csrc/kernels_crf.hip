@@ -323,6 +323,7 @@ void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStre
         case 7: lattice_points_kernel<7><<<grid, block, 0, s>>>(L, fs); break;
         default: break;
     }
+    RV_LAUNCHED("lattice_points_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,6 +655,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     lattice_compact_kernel<<<dim3((cap + 255) / 256), dim3(256), 0, s>>>(L);
     const long long nb_threads = (long long)L.m_bound * (L.d + 1);
     lattice_neighbours_kernel<<<dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, s>>>(L);
+    RV_LAUNCHED("lattice_compact_kernel / lattice_neighbours_kernel");
     if (csr_fast_path(L) && sb.block_hist) {
         const int mcap = (int)((L.cap_f_mask + 1) / 2);
         const int wbpf = (L.N + CS_PIX - 1) / CS_PIX;
@@ -666,6 +668,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        RV_LAUNCHED("csr_pass_kernel / csr_scan_kernel / csr_scatter_kernel");
     } else {
         lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
         // stable radix sort by vertex id: equal keys keep ascending entry (= point) order
@@ -673,6 +676,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, sb.vals_out, (size_t)n_entries, 0,
                                         (unsigned)sb.key_bits, s);
         lattice_csr_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_out, sb.vals_out, n_entries);
+        RV_LAUNCHED("lattice_remap_kernel / radix sort / lattice_csr_kernel");
     }
     launch_vertex_order(L, sb, s);
 }
@@ -703,6 +707,7 @@ void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s) {
     vertex_len_kernel<<<dim3((unsigned)((L.m_bound + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, len_shift);
     size_t temp = sb.temp_bytes;
     (void)rocprim::radix_sort_pairs(sb.temp, temp, sb.keys_in, sb.keys_out, sb.vals_in, L.vorder, (size_t)L.m_bound, 0, 32, s);
+    RV_LAUNCHED("vertex_len_kernel / radix sort");
 }
 
 size_t scan_temp_bytes(unsigned cap) {
@@ -731,6 +736,7 @@ csr_norm_kernel(const uint2* __restrict__ csr_pw, const float* __restrict__ norm
 
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s) {
     csr_norm_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L.csr_pw, L.norm, L.csr_nrm, n_entries, L.counters);
+    RV_LAUNCHED("csr_norm_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,11 +773,11 @@ static_assert(SPLAT_RE % SPLAT_RR == 0, "ring positions are compile-time: the ro
 // at the price of 7/6 as many block-steps; chunks with many frames are bandwidth bound and keep GV = G.
 // FAST: the input is this library's own Q * norm (finite, >= 0) in one contiguous [point][C] matrix: a padding lane's
 // product is 0 * x = +0 by itself (no select), and the row address needs no per-frame split.
-// One item of the list-major walk: G vertices of one frame, whole lists (or their piece inside `band`).  The kernel
-// below runs one item per block; the resident kernel falls back to a loop over these items when its planner gave up.
+// One item of the list-major walk: G vertices of one frame, whole lists.  The kernel below runs one item per block; the
+// resident kernel falls back to a loop over these items when its planner gave up.
 template <int MODE, int CC, bool FULL, int GV, bool FAST>
 __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const ValueView& src, int C, int c0, int n_store, float* __restrict__ values,
-                                                 int band, unsigned item, float (*prod)[GV][CC][68]) {
+                                                 unsigned item, float (*prod)[GV][CC][68]) {
     constexpr int G = GV;
     constexpr int AW = (GV < SplatGroup<CC>::G && GV >= 4) ? 3 : GV;   // the adder's wave index
     const int lane = threadIdx.x & 63;
@@ -798,15 +804,7 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             const unsigned idx = r * G + i;
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
-                unsigned k0 = L.vstart[v], k1 = L.vend[v];
-                if (L.n_bands > 1) {   // this launch sums the list's piece inside band `band`; `values` carries the chain
-                    const int f = (int)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
-                    const int f0 = L.fstart[f], Mf = L.fstart[f + 1] - f0;
-                    const unsigned* fb = L.bh + (size_t)L.wbpf * f0 + ((int)v - f0);
-                    const int w0 = band * L.band_wb, w1 = w0 + L.band_wb;
-                    k0 = fb[(size_t)w0 * Mf];
-                    if (w1 < L.wbpf) k1 = fb[(size_t)w1 * Mf];
-                }
+                const unsigned k0 = L.vstart[v], k1 = L.vend[v];
                 const unsigned nt = (k1 - k0 + 63u) / 64u;
                 n_steps = nt > n_steps ? nt : n_steps;
                 if (i == pw && wave != AW) { my_k0 = k0; my_k1 = k1; }
@@ -888,7 +886,6 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             const bool mine = lane < G * CC && idx < n_vert && c < n_store;
             const unsigned cv = mine ? L.vorder[gstart + idx] : 0u;
             float acc = 0.0f;
-            if (band > 0 && mine) acc = values[(size_t)cv * C + c0 + c];   // running sum of the earlier bands
             __syncthreads();
             for (unsigned t = 0; t < n_steps; t++) {
                 const float* pr = prod[t & 1u][gi][c];
@@ -906,11 +903,10 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
 
 template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
 __global__ void __launch_bounds__((GV + 1) * 64)
-splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values, int band) {
+splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
     __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][68];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
-    if (L.skip_if_queue && L.skip_if_queue[0]) return;   // the band-major queue schedule did this splat
-    splat_group_item<MODE, CC, FULL, GV, FAST>(L, src, C, c0, n_store, values, band, blockIdx.x, prod);
+    splat_group_item<MODE, CC, FULL, GV, FAST>(L, src, C, c0, n_store, values, blockIdx.x, prod);
 }
 
 template <int MODE, int CC, int GV, bool FAST>
@@ -921,10 +917,9 @@ static void splat_group_launch_g(const LatticeDev& L, const ValueView& src, int 
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned per_group = nfg * (unsigned)((max_mf + G - 1) / G);
     const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
-    for (int band = 0; band < L.n_bands; band++) {
-        if (n == CC) splat_group_kernel<MODE, CC, true, GV, FAST><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
-        else splat_group_kernel<MODE, CC, false, GV, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values, band);
-    }
+    if (n == CC) splat_group_kernel<MODE, CC, true, GV, FAST><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    else splat_group_kernel<MODE, CC, false, GV, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    RV_LAUNCHED("splat_group_kernel");
 }
 
 template <int MODE, int CC>
@@ -942,13 +937,9 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
     else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
 }
 
-template <int CC>
-static void splat_queue_launch(const LatticeDev& L, const SplatQueueDev& q, const ValueView& src, float* values, hipStream_t s);
-
-// RVSEG_SPLAT_GV (timing experiments): 0 = choose by the chunk's shape (default), 6 / 7 = force for C = 8, 9
+// vertices per block of the list-major walk for C = 8, 9 (rvseg_schedule.group_vertices: 0 = by the chunk's shape)
 static int splat_gv_choice(const LatticeDev& L) {
-    static const int forced = std::getenv("RVSEG_SPLAT_GV") ? std::atoi(std::getenv("RVSEG_SPLAT_GV")) : 0;
-    if (forced == 6 || forced == 7) return forced;
+    if (L.group_vertices == 6 || L.group_vertices == 7) return L.group_vertices;
     // few frames: the launch waits for its longest chains (steps x step time), so the shorter step wins;
     // many frames: the launch is bound by the bytes it moves, the block count only adds overhead
     return L.n_frames <= 16 ? 6 : 7;
@@ -958,29 +949,19 @@ template <int CC>
 static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s);
 
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
-                  const SplatQueueDev* queue, const SplatResidentDev* resident, int slot) {
+                  const SplatResidentDev* resident, int slot) {
     if (mode == 2) {
         splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
-    if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8) && resident) {
+    if (mode == 0 && own_q && contig && (C == 9 || C == 8) && resident) {
         // resident band schedule (the kernel walks the lists the list-major way itself should the planner have given up)
         const bool ran = C == 9 ? splat_resident_launch<9>(L, *resident, src.base, values, slot, s)
                                 : splat_resident_launch<8>(L, *resident, src.base, values, slot, s);
         if (ran) return;
     }
-    if (mode == 0 && own_q && contig && L.n_bands == 1 && C == 9 && queue) {
-        // experimental band-major schedule; the regular launch below stands by and returns at once when the queue is valid
-        splat_queue_launch<9>(L, *queue, src, values, s);
-        LatticeDev L2 = L;
-        L2.skip_if_queue = queue->flags;
-        const int gv = splat_gv_choice(L);
-        if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L2, src, C, 0, 9, values, s);
-        else splat_group_launch_g<0, 9, 7, true>(L2, src, C, 0, 9, values, s);
-        return;
-    }
-    if (mode == 0 && own_q && contig && L.n_bands == 1 && (C == 9 || C == 8)) {
+    if (mode == 0 && own_q && contig && (C == 9 || C == 8)) {
         // the mean-field loop's own input (Q * norm written by the previous update): the fast producer, and the
         // block shape chosen for the chunk
         const int gv = splat_gv_choice(L);
@@ -998,240 +979,6 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         if (mode == 0) splat_group_pass<0>(L, src, C, c0, n, values, s);
         else splat_group_pass<1>(L, src, C, c0, n, values, s);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Band-major work queue (experimental schedule of the ordered splat, RVSEG_SPLAT_QUEUE=1).
-// a vertex-major walk reads every Q row d+1 times at unrelated moments; if all pieces of a
-// frame's lists inside one pixel band are summed at about the same time, the re-reads meet in the XCD's L2.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void queue_piece(const LatticeDev& L, const SplatQueueDev& q, int f0, int Mf, int lv, int band,
-                                            unsigned& k0, unsigned& k1) {
-    const unsigned* fb = L.bh + (size_t)L.wbpf * f0 + lv;
-    const int w0 = band * q.band_wb, w1 = w0 + q.band_wb;
-    k0 = fb[(size_t)w0 * Mf];
-    k1 = w1 < L.wbpf ? fb[(size_t)w1 * Mf] : L.vend[f0 + lv];
-}
-
-// FILL = false: groups of every (frame, band); FILL = true: the items, longest first, seven to a group
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-queue_items_kernel(LatticeDev L, SplatQueueDev q) {
-    extern __shared__ unsigned qn[];   // piece lengths of the frame's vertices in this band
-    __shared__ unsigned s_cnt;
-    if (L.counters[1]) return;
-    const int frame = blockIdx.x / q.n_bands, band = blockIdx.x - frame * q.n_bands;
-    const int f0 = L.fstart[frame], Mf = L.fstart[frame + 1] - f0;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    unsigned mine = 0;
-    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
-        unsigned k0, k1;
-        queue_piece(L, q, f0, Mf, lv, band, k0, k1);
-        qn[lv] = k1 - k0;
-        mine += k1 > k0 ? 1u : 0u;
-    }
-    if (mine) atomicAdd(&s_cnt, mine);
-    __syncthreads();
-    const int x = frame % q.NQ, slot = frame / q.NQ;
-    const unsigned cell = (unsigned)x * (unsigned)(q.n_bands * q.nfq) + (unsigned)band * q.nfq + slot;
-    const unsigned cnt = s_cnt, groups = (cnt + 6u) / 7u;
-    if (!FILL) {
-        if (threadIdx.x == 0) q.grp_cnt[cell] = groups;
-        return;
-    }
-    if (!q.flags[0]) return;   // more groups than the queue can hold: the regular schedule runs instead
-    QueueItem* out = q.items + ((size_t)q.q_base[x] + q.grp_off[cell]) * 7;
-    for (int lv = threadIdx.x; lv < Mf; lv += 256) {
-        const unsigned n = qn[lv];
-        if (!n) continue;
-        unsigned rank = 0;   // pieces that are longer, or as long with a lower vertex number
-        for (int u = 0; u < Mf; u++) { const unsigned m = qn[u]; rank += (m > n || (m == n && u < lv)) ? 1u : 0u; }
-        unsigned k0, k1;
-        queue_piece(L, q, f0, Mf, lv, band, k0, k1);
-        QueueItem it;
-        it.v = f0 + lv; it.k0 = k0; it.k1 = k1;
-        it.flags = 1u | (k0 == L.vstart[f0 + lv] ? 2u : 0u) | (k1 == L.vend[f0 + lv] ? 4u : 0u);
-        out[q.ascending ? cnt - 1u - rank : rank] = it;
-    }
-    for (unsigned r = cnt + threadIdx.x; r < groups * 7u; r += 256) { QueueItem it; it.v = -1; it.k0 = 0; it.k1 = 0; it.flags = 0; out[r] = it; }
-}
-
-__global__ void __launch_bounds__(64)
-queue_scan_kernel(SplatQueueDev q) {
-    __shared__ unsigned tot[64];
-    const int x = threadIdx.x;
-    if (x < q.NQ) {
-        const unsigned n = (unsigned)(q.n_bands * q.nfq);
-        unsigned run = 0;
-        for (unsigned i = 0; i < n; i++) { const unsigned c = q.grp_cnt[(size_t)x * n + i]; q.grp_off[(size_t)x * n + i] = run; run += c; }
-        tot[x] = run;
-        q.q_total[x] = run;
-    }
-    __syncthreads();
-    if (x == 0) {
-        unsigned run = 0;
-        for (int y = 0; y < q.NQ; y++) { q.q_base[y] = run; run += tot[y]; }
-        q.flags[0] = run <= q.cap_groups ? 1 : 0;
-    }
-}
-
-void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s) {
-    const int mcap = (int)((L.cap_f_mask + 1) / 2);
-    const dim3 grid((unsigned)(L.n_frames * q.n_bands));
-    queue_items_kernel<false><<<grid, dim3(256), (size_t)mcap * 4, s>>>(L, q);
-    queue_scan_kernel<<<dim3(1), dim3(64), 0, s>>>(q);
-    queue_items_kernel<true><<<grid, dim3(256), (size_t)mcap * 4, s>>>(L, q);
-}
-
-// The splat over the queue: a persistent grid; a block takes the next group of its XCD's queue (the queues of the
-// other XCDs once its own is empty), runs the seven pieces exactly like splat_group_kernel runs seven lists --
-// producers form the products of a 64-entry tile, the adder sums them in list order -- and hands every chain on:
-// the adder waits until its vertex has been summed up to the piece's first entry, loads the running sums, and
-// publishes the new position when they are stored.  Sums and positions move with agent-scope (sc1) accesses.
-// Groups are numbered band-major, so whatever a piece waits for has a lower ticket in the same queue and is done or
-// running: the waits cannot deadlock; they are bounded all the same (flags[1] records a time-out).
-// Rings of the queue kernel.  A piece is short (5.5 tiles on average at 4096-pixel bands) and its rows are L2
-// resident after the band's first reader, so shallow rings do; what counts is how many groups a CU holds at once
-// (their start-up latencies -- ticket, descriptors, CSR, rows: three dependent memory round trips -- overlap only
-// across groups): 8 / 4 tiles of look-ahead keep the kernel under 80 VGPRs, i.e. three blocks per CU instead of two.
-constexpr int QRE = 8, QRR = 4;
-static_assert(QRE % QRR == 0, "ring positions are compile-time");
-
-template <int CC>
-__global__ void __launch_bounds__((SplatGroup<CC>::G + 1) * 64, 6)
-splat_queue_kernel(LatticeDev L, SplatQueueDev q, ValueView src, float* __restrict__ values) {
-    constexpr int G = SplatGroup<CC>::G;
-    constexpr int C = CC;
-    __shared__ __attribute__((aligned(16))) float prod[2][G][CC][68];
-    __shared__ unsigned s_group[2];
-    if (L.counters[1] || !q.flags[0]) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // thread 0 of the block runs the ticket machine: the next group is drawn while the current one is being summed
-    int qq = q.NQ > 1 ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) % q.NQ : 0;   // HW_REG_XCC_ID[3:0]; placement is for speed only
-    int tried = 0;
-    auto draw = [&]() -> unsigned {
-        for (; tried < q.NQ; ) {
-            const unsigned t = atomicAdd(&q.head[qq], 1u);
-            if (t < q.q_total[qq]) return q.q_base[qq] + t;
-            tried++;
-            qq = (qq + 1) % q.NQ;
-        }
-        return 0xFFFFFFFFu;
-    };
-    unsigned next_group = 0xFFFFFFFFu;
-    if (threadIdx.x == 0) { next_group = draw(); s_group[0] = next_group; }
-    __syncthreads();
-    for (unsigned round = 0;; round++) {
-        const unsigned group = s_group[round & 1u];
-        if (group == 0xFFFFFFFFu) return;
-        if (threadIdx.x == 0) next_group = draw();   // a returning atomic: waited for only where it is stored, at the end
-        const QueueItem* its = q.items + (size_t)group * 7;
-        const unsigned long long t_pick = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        unsigned n_steps = 0, my_k0 = 0, my_k1 = 0;
-        for (int i = 0; i < G; i++) {
-            const QueueItem it = its[i];
-            const unsigned nt = (it.k1 - it.k0 + 63u) / 64u;
-            n_steps = nt > n_steps ? nt : n_steps;
-            if (i == wave) { my_k0 = it.k0; my_k1 = it.k1; }
-        }
-        if (wave == G) __builtin_amdgcn_s_setprio(3);
-        if (wave < G) {
-            const bool has = my_k1 > my_k0;
-            const unsigned kc0 = has ? my_k0 : 0u, kc1 = has ? my_k1 : 1u;
-            const unsigned n_tiles = has ? (my_k1 - my_k0 + 63u) / 64u : 0u;
-            float x[QRR][CC];
-            float w[QRE];
-            unsigned pix[QRE];
-#pragma unroll
-            for (int r = 0; r < QRE; r++) { w[r] = 0.f; pix[r] = 0u; }
-            auto load_entries = [&](unsigned tile, int slot) {
-                unsigned k = kc0 + tile * 64u + lane;
-                k = k < kc1 ? k : kc1 - 1u;
-                const uint2 pw = L.csr_pw[k];
-                w[slot] = __uint_as_float(pw.y);
-                pix[slot] = pw.x;
-            };
-            auto gather_rows = [&](int eslot, int rslot) { load_row<CC>(src.base + (size_t)pix[eslot] * (unsigned)C, x[rslot]); };
-#pragma unroll
-            for (int i = 0; i < QRE - 1; i++) load_entries((unsigned)i, i);
-#pragma unroll
-            for (int i = 0; i < QRR - 1; i++) gather_rows(i, i);
-            auto stage = [&](unsigned t, auto S) -> bool {
-                constexpr int s = decltype(S)::value;
-                if (t >= n_steps) return false;
-                const unsigned base = my_k0 + t * 64u;
-                const unsigned n_valid = t < n_tiles ? (my_k1 - base < 64u ? my_k1 - base : 64u) : 0u;
-                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
-                float (*pb)[68] = prod[t & 1u][wave];
-#pragma unroll
-                for (int c = 0; c < CC; c++) pb[c][lane] = wl * x[s % QRR][c];   // +0 past the piece (finite rows)
-                load_entries(t + QRE - 1, (s + QRE - 1) % QRE);
-                gather_rows((s + QRR - 1) % QRE, (s + QRR - 1) % QRR);
-                __syncthreads();
-                return true;
-            };
-#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
-            for (unsigned t0 = 0;; t0 += QRE) {
-                RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
-            }
-#undef RV_ST
-            __syncthreads();
-        } else {
-            const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
-            const QueueItem it = its[gi];
-            const bool mine = lane < G * CC && (it.flags & 1u);
-            const unsigned my_tiles = mine ? (it.k1 - it.k0 + 63u) / 64u : 0u;
-            // the chain travels as one 8-byte granule per (vertex, class): {running sum, list position it is valid for},
-            // written by ONE sc1 store and polled by ONE sc1 load -- data and flag cannot be seen apart
-            unsigned long long* gran = q.vacc + ((size_t)(mine ? it.v : 0) * C + c);
-            float acc = 0.0f;
-            if (mine && !(it.flags & 2u)) {
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned long long gval = __hip_atomic_load(gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(gval >> 32) == it.k0) { acc = __uint_as_float((unsigned)gval); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 17)) { q.flags[1] = 1; break; }
-                }
-            }
-            const unsigned long long t_deps = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            __syncthreads();
-            const unsigned long long t_go = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            for (unsigned t = 0; t < n_steps; t++) {
-                const float* pr = prod[t & 1u][gi][c];
-                float4 qv[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) qv[i] = reinterpret_cast<const float4*>(pr)[i];
-#pragma unroll
-                for (int i = 0; i < 16; i++) { acc += qv[i].x; acc += qv[i].y; acc += qv[i].z; acc += qv[i].w; }
-                if (q.trace && lane == 0 && t + 1u == n_steps) {
-                    unsigned long long* tr = q.trace + (size_t)group * 4;
-                    tr[0] = t_pick; tr[1] = t_deps; tr[2] = __builtin_amdgcn_s_memrealtime(); tr[3] = ((unsigned long long)n_steps << 32) | (unsigned)(t_go - t_deps);
-                }
-                if (t + 1u == my_tiles) {
-                    // this piece is complete (shorter pieces of the group do not wait for the longest): hand the chain on
-                    __hip_atomic_store(gran, ((unsigned long long)it.k1 << 32) | (unsigned long long)__float_as_uint(acc),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (it.flags & 4u) values[(size_t)it.v * C + c] = acc;   // the vertex's last piece: the blur reads `values`
-                }
-                __syncthreads();
-            }
-        }
-        if (threadIdx.x == 0) s_group[(round + 1u) & 1u] = next_group;
-        __syncthreads();   // the product buffers are free again, the next group is known
-    }
-}
-
-template <int CC>
-static void splat_queue_launch(const LatticeDev& L, const SplatQueueDev& q, const ValueView& src, float* values, hipStream_t s) {
-    constexpr int G = SplatGroup<CC>::G;
-    static const int per_cu = std::getenv("RVSEG_SPLAT_QUEUE_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_BLOCKS_PER_CU")) : 3;
-    (void)hipMemsetAsync(q.head, 0, 64 * sizeof(unsigned), s);
-    // vertices without entries (the lattice's padding points create some) get no piece: their sums are the zeros below
-    (void)hipMemsetAsync(values, 0, (size_t)L.m_bound * CC * sizeof(float), s);   // (granule tags of earlier launches are harmless: no piece of this one waits for a position an earlier launch left behind)
-    splat_queue_kernel<CC><<<dim3((unsigned)(256 * per_cu)), dim3((G + 1) * 64), 0, s>>>(L, q, src, values);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1493,6 +1240,7 @@ void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStr
     resident_plan_kernel<<<dim3((unsigned)L.n_frames), dim3(RES_PLAN_THREADS), dyn, s>>>(L, R, heavy_cap);
     resident_seal_kernel<<<dim3(1), dim3(1), 0, s>>>(L, R);
     resident_fill_kernel<<<dim3((unsigned)((R.B * R.n_bands + 3) / 4), (unsigned)L.n_frames), dim3(256), 0, s>>>(L, R);
+    RV_LAUNCHED("resident_plan_kernel / resident_seal_kernel / resident_fill_kernel");
 }
 
 // The splat over the schedule.  Block (frame, j): 7 producer waves + the adder, as in splat_group_kernel; the tile
@@ -1523,7 +1271,7 @@ splat_resident_kernel(LatticeDev L, SplatResidentDev R, ValueView srcv, float* _
         // the planner gave up on some frame (more vertices or tiles than its tables hold): this grid walks the lists
         // the list-major way, G vertices per item
         for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
-            splat_group_item<0, CC, true, G, true>(L, srcv, CC, 0, CC, values, 0, item, reinterpret_cast<float (*)[G][CC][68]>(res_lds));
+            splat_group_item<0, CC, true, G, true>(L, srcv, CC, 0, CC, values, item, reinterpret_cast<float (*)[G][CC][68]>(res_lds));
             __syncthreads();
         }
         return;
@@ -1752,36 +1500,54 @@ static size_t resident_lds_bytes(int CC, int TH) {
     return ((size_t)2 * 7 * CC * (TH + 4) + (size_t)(RES_MAX_OWNV + 1) * CC) * sizeof(float) + 2 * 64 * 8 * sizeof(unsigned);
 }
 
-// more than 64 KB of dynamic LDS has to be asked for, once per instantiation
+// more than 64 KB of dynamic LDS has to be asked for, once per instantiation AND device (one process may drive
+// several GPUs, one context each: rvseg_comm.cpp)
+constexpr int RES_MAX_DEVICES = 64;
 template <int CC, int TH>
 static bool resident_setup() {
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(splat_resident_kernel<CC, 8, 4, TH>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(CC, TH));
-    return e == hipSuccess;
+    static std::atomic<int> state[RES_MAX_DEVICES];   // 0 = not tried, 1 = ok, 2 = refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RES_MAX_DEVICES) return false;
+    int st = state[dev].load();
+    if (st == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(splat_resident_kernel<CC, 8, 4, TH>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds_bytes(CC, TH));
+        if (e != hipSuccess) (void)hipGetLastError();   // refused: the caller walks the lists the list-major way
+        st = e == hipSuccess ? 1 : 2;
+        state[dev].store(st);
+    }
+    return st == 1;
 }
 
-static int g_resident_cus = 0;
-int resident_cu_count() { (void)resident_block_capacity(64); return g_resident_cus; }
-
-int resident_block_capacity(int chunk) {
-    static int cap[2] = {-1, -1};
+// blocks of the resident kernel that fit on the current device at once, and its CU count (cached per device)
+static bool resident_device_info(int chunk, int* capacity, int* cus) {
+    static std::atomic<int> cap[RES_MAX_DEVICES][2], ncu[RES_MAX_DEVICES];   // 0 = not known yet, -1 = failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RES_MAX_DEVICES) return false;
     const int which = chunk == 128 ? 1 : 0;
-    if (cap[which] < 0) {
-        int dev = 0, per_cu = 0;
+    if (cap[dev][which].load() == 0) {
+        int per_cu = 0;
         hipDeviceProp_t pr;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipGetDeviceProperties(&pr, dev);
+        hipError_t e = hipGetDeviceProperties(&pr, dev);
         if (e == hipSuccess) {
             if (which) e = resident_setup<9, 128>() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4, 128>, 512, resident_lds_bytes(9, 128)) : hipErrorUnknown;
             else e = resident_setup<9, 64>() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, splat_resident_kernel<9, 8, 4, 64>, 512, resident_lds_bytes(9, 64)) : hipErrorUnknown;
         }
-        cap[which] = e == hipSuccess ? per_cu * pr.multiProcessorCount : 0;
-        if (e == hipSuccess) g_resident_cus = pr.multiProcessorCount;
+        if (e != hipSuccess) (void)hipGetLastError();
+        ncu[dev].store(e == hipSuccess ? pr.multiProcessorCount : -1);
+        cap[dev][which].store(e == hipSuccess && per_cu > 0 ? per_cu * pr.multiProcessorCount : -1);
     }
-    return cap[which];
+    const int c = cap[dev][which].load(), n = ncu[dev].load();
+    if (capacity) *capacity = c > 0 ? c : 0;
+    if (cus) *cus = n > 0 ? n : 0;
+    return c > 0;
 }
 
-// false: the kernel could not be set up (its dynamic LDS was refused): the caller walks the lists the list-major way
+int resident_cu_count() { int n = 0; (void)resident_device_info(128, nullptr, &n); return n; }
+int resident_block_capacity(int chunk) { int c = 0; (void)resident_device_info(chunk, &c, nullptr); return c; }
+
+// false: the kernel could not be set up or launched (its dynamic LDS was refused): the caller walks the lists the
+// list-major way
 template <int CC>
 static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R, const float* src, float* values, int slot, hipStream_t s) {
     const unsigned NG = (unsigned)L.n_groups;
@@ -1800,7 +1566,7 @@ static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
         if (!resident_setup<CC, 64>()) return false;
         splat_resident_kernel<CC, 8, 4, 64><<<grid, block, resident_lds_bytes(CC, 64), s>>>(L, R, sv, values, tag, slot, n_items);
     }
-    return true;
+    return hipGetLastError() == hipSuccess;   // a refused launch is a refused set-up: fall back
 }
 
 int csr_pix_per_block() { return CS_PIX; }
@@ -1889,6 +1655,7 @@ float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a,
     if (L.cap_f_mask + 1 <= 8192u) {   // at most 4096 vertices per frame: one block per frame is enough
         if (seq) blur_frames_kernel<true><<<dim3((unsigned)L.n_frames), dim3(small_blocks ? 256 : 1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
         else blur_frames_kernel<false><<<dim3((unsigned)L.n_frames), dim3(small_blocks ? 256 : 1024), 0, s>>>(L, C, reverse ? 1 : 0, a, b);
+        RV_LAUNCHED("blur_frames_kernel");
         return b;
     }
     const long long total = (long long)L.m_bound * C;
@@ -1900,6 +1667,7 @@ float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a,
         else blur_kernel<false><<<grid, block, 0, s>>>(L, axis, C, cur, nxt);
         float* tmp = cur; cur = nxt; nxt = tmp;
     }
+    RV_LAUNCHED("blur_kernel");
     return cur;
 }
 
@@ -1975,6 +1743,7 @@ void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const floa
         if (L.d == 6) slice_norm_kernel<7><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
         else if (L.d == 5) slice_norm_kernel<6><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
         else slice_norm_kernel<3><<<g1, b1, 0, s>>>(L, values, alpha, out, n_points);
+        RV_LAUNCHED("slice_norm_kernel");
         return;
     }
     const long long total = n_points * C;
@@ -1986,6 +1755,7 @@ void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const floa
         if (out_mode == 0) RV_SLICE(false, 0); else if (out_mode == 1) RV_SLICE(false, 1); else RV_SLICE(false, 2);
     }
 #undef RV_SLICE
+    RV_LAUNCHED("slice_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2004,6 +1774,7 @@ neg_unary_kernel(ValueView unary, int negate, int C, int N, float* __restrict__ 
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s) {
     const long long total = n_points * C;
     neg_unary_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(unary, negate ? 1 : 0, C, N, tmp, n_points);
+    RV_LAUNCHED("neg_unary_kernel");
 }
 
 __global__ void __launch_bounds__(256)
@@ -2027,6 +1798,7 @@ softmax_kernel(const float* __restrict__ tmp, int C, int N, ValueView q, long lo
 
 void launch_softmax(const float* tmp, int C, int N, const ValueView& q, long long n_points, hipStream_t s) {
     softmax_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(tmp, C, N, q, n_points);
+    RV_LAUNCHED("softmax_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2153,6 +1925,9 @@ mf_update_kernel(LatticeDev L, const float* __restrict__ values, float alpha, fl
     }
 }
 
+// class counts with a fused softmax_unary / mf_update instantiation (the switch lists below)
+bool mf_fused_supported(int C) { return (C >= 2 && C <= 10) || C == 12 || C == 16 || C == 21; }
+
 // returns false when C has no fused instantiation (the caller then runs the unfused kernels)
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
                       const ValueView& Q, bool scale_out, const MfLabels& lab, hipStream_t s) {
@@ -2162,6 +1937,7 @@ bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg
 #define RV_MF(SEQ, CC)                                                                                            \
     if (L.d == 6) mf_update_kernel<SEQ, CC, 7><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0, lab); \
     else mf_update_kernel<SEQ, CC, 0><<<grid, block, MF_LDS_BYTES, s>>>(L, values, alpha, neg_w, unary, negate ? 1 : 0, Q, scale_out ? 1 : 0, lab); \
+    RV_LAUNCHED("mf_update_kernel"); \
     return true
     switch (C) {
         case 2: RV_MF(true, 2);
@@ -2214,7 +1990,7 @@ softmax_unary_kernel(ValueView unary, int negate, int N, ValueView q, long long 
 bool launch_softmax_unary(const ValueView& unary, bool negate, int C, int N, const ValueView& q, long long n_points,
                           const float* scale, hipStream_t s) {
     const dim3 grid((unsigned)((n_points + 255) / 256)), block(256);
-#define RV_SU(CC) softmax_unary_kernel<CC><<<grid, block, 0, s>>>(unary, negate ? 1 : 0, N, q, n_points, scale); return true
+#define RV_SU(CC) softmax_unary_kernel<CC><<<grid, block, 0, s>>>(unary, negate ? 1 : 0, N, q, n_points, scale); RV_LAUNCHED("softmax_unary_kernel"); return true
     switch (C) {
         case 2: RV_SU(2); case 3: RV_SU(3); case 4: RV_SU(4); case 5: RV_SU(5); case 6: RV_SU(6); case 7: RV_SU(7);
         case 8: RV_SU(8); case 9: RV_SU(9); case 10: RV_SU(10); case 12: RV_SU(12); case 16: RV_SU(16); case 21: RV_SU(21);
@@ -2232,6 +2008,7 @@ fill_int_kernel(int* p, int v, long long n) {
 void launch_fill_int(int* p, int v, long long n, hipStream_t s) {
     if (n <= 0) return;
     fill_int_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(p, v, n);
+    RV_LAUNCHED("fill_int_kernel");
 }
 
 }  // namespace rvseg

@@ -461,11 +461,13 @@ void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb,
     const size_t total = (size_t)g.W * g.H * n;
     prep_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
         g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, d_change, n);
+    RV_LAUNCHED("prep_kernel");
 }
 
 void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_change, uint8_t* d_rect, int n, hipStream_t s) {
     const int tiles = ((g.W + DM_TW - 1) / DM_TW) * ((g.H + DM_TH - 1) / DM_TH);
     window_map_kernel<<<dim3((unsigned)(tiles * n)), dim3(64), 0, s>>>(g, d_change, d_rect);
+    RV_LAUNCHED("window_map_kernel");
 }
 
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
@@ -487,17 +489,17 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
         }
         const int tiles_x = (g.lw + NF_TX - 1) / NF_TX, tiles_y = (g.lh + NF_TY - 1) / NF_TY;
         const int n_jobs = tiles_x * tiles_y * n;
-        // one tile per block by default: a grid of long-lived blocks (RVSEG_NF_BLOCKS_PER_CU = 2..8) runs this kernel
-        // alone as fast (747-774 vs 759 us) but keeps the lattice build on the side stream off the CUs for its whole
-        // duration (build 3.5 -> 5.3 ms, step +0.3 ms)
-        static const int per_cu = std::getenv("RVSEG_NF_BLOCKS_PER_CU") ? std::atoi(std::getenv("RVSEG_NF_BLOCKS_PER_CU")) : 0;
-        const int grid = per_cu > 0 ? std::min(n_jobs, 256 * per_cu) : n_jobs;
-        normal_feature_tiled_kernel<<<dim3((unsigned)grid), dim3(NF_THREADS), lds, s>>>(
+        // one tile per block: a grid of 2..8 long-lived blocks per CU was measured to run this kernel alone as fast
+        // (747-774 vs 759 us) but keeps the lattice build on the side stream off the CUs for its whole duration
+        // (build 3.5 -> 5.3 ms, step +0.3 ms)
+        normal_feature_tiled_kernel<<<dim3((unsigned)n_jobs), dim3(NF_THREADS), lds, s>>>(
             g, d_cloud, d_rect, d_nfeat, tiles_x, tiles_y, n_jobs);
+        RV_LAUNCHED("normal_feature_tiled_kernel");
         return;
     }
     const int total = g.lw * g.lh * n;
     normal_feature_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, d_cloud, d_rect, d_nfeat, n);
+    RV_LAUNCHED("normal_feature_kernel");
 }
 
 }  // namespace rvseg

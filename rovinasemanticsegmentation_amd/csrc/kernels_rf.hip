@@ -91,6 +91,7 @@ void launch_forest_eval(const DeviceForest& f, const float* d_X, int P, int D, f
         forest_eval_kernel<4><<<dim3((unsigned)((threads + block - 1) / block)), dim3(block), 0, s>>>(
             nodes, roots, hist, f.n_trees, f.sum_classes, d_X, P, D, d_out);
     }
+    RV_LAUNCHED("forest_eval_kernel");
 }
 
 }  // namespace rvseg
@@ -472,13 +473,13 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
     const size_t smem = (size_t)WAVES_PER_BLOCK * (PPW * fb_stride + PPW * 32);
     const int pts_per_block = PPW * WAVES_PER_BLOCK;
     const dim3 grid((unsigned)((total + pts_per_block - 1) / pts_per_block)), block(64 * WAVES_PER_BLOCK);
-    static const bool eager = getenv("RVSEG_RF_EAGER") && atoi(getenv("RVSEG_RF_EAGER")) != 0;   // A/B timing only
-    if (!d_dump && !eager && n_trees_ok(f.n_trees)) {
+    if (!d_dump && n_trees_ok(f.n_trees)) {
         const size_t rt_bytes = (size_t)g.rt_rows * sizeof(ResizeRow);
         const int in_lds = g.n_patch > 0 && rt_bytes <= 40 * 1024 ? 1 : 0;   // else the records come through L1
         rf_frames_lazy_kernel<<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(
             g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(), f.n_trees, d_rt, in_lds, d_lab, d_depth,
             d_cloud, d_nfeat, d_low, total);
+        RV_LAUNCHED("rf_frames_lazy_kernel");
         return;
     }
     if (d_dump)
@@ -487,6 +488,7 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
     else
         rf_frames_kernel<false><<<grid, block, smem, s>>>(g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(),
                                                           f.n_trees, d_rt, d_lab, d_depth, d_cloud, d_nfeat, d_low, d_dump, d_valid, total, fb_stride);
+    RV_LAUNCHED("rf_frames_kernel");
 }
 
 // =============================================================================================
@@ -593,6 +595,7 @@ void launch_upsample_pack(const FrameGeom& g, const DeviceForest& f, const Upsam
 #undef RV_UP
         prefix += C;
     }
+    RV_LAUNCHED("upsample_pack_kernel");
 }
 
 // =============================================================================================
@@ -630,11 +633,13 @@ void launch_labels_frames(const float* d_values, int n_frames, int N, const Devi
             unknown[l], d_labels);
         prefix += f.class_counts[l];
     }
+    RV_LAUNCHED("labels_frames_kernel");
 }
 
 void launch_labels(const float* d_values, size_t n_points, int C, int mode, int unknown, int8_t* d_labels, hipStream_t s) {
     if (n_points == 0) return;
     labels_kernel<<<dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, s>>>(d_values, n_points, C, mode, unknown, d_labels);
+    RV_LAUNCHED("labels_kernel");
 }
 
 }  // namespace rvseg

@@ -22,6 +22,21 @@ bool hip_ok(rvseg_ctx* ctx, hipError_t e, const char* what) {
     return false;
 }
 
+static thread_local std::string t_launch_err;
+
+void launch_check(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && t_launch_err.empty()) t_launch_err = std::string("kernel launch failed: ") + what + ": " + hipGetErrorString(e);
+}
+
+rvseg_status launch_error_take(rvseg_ctx* ctx) {
+    launch_check("(runtime)");
+    if (t_launch_err.empty()) return RVSEG_OK;
+    if (ctx) ctx->err = t_launch_err;
+    t_launch_err.clear();
+    return RVSEG_ERR_HIP;
+}
+
 rvseg_status dev_alloc(rvseg_ctx* ctx, DevBuf& b, size_t bytes) {
     dev_free(b);
     if (bytes == 0) bytes = 16;
@@ -171,6 +186,28 @@ void rvseg_params_default(rvseg_params* p) {
     p->lattice_capacity_log2 = 0;
 }
 
+void rvseg_schedule_default(rvseg_schedule* s) {
+    if (!s) return;
+    std::memset(s, 0, sizeof(*s));
+    s->resident_band = 16;
+    s->resident_chunk = 128;
+    s->resident_window = -1;
+    s->overlap_build = 1;
+    s->overlap_layers = 1;
+}
+
+rvseg_status rvseg_set_schedule(rvseg_ctx* ctx, const rvseg_schedule* s) {
+    if (!ctx) return RVSEG_ERR_INVALID_ARG;
+    if (!s || s->splat < 0 || s->splat > 2 || s->resident_blocks < 0 || s->resident_blocks > 16 || s->resident_band < 1 ||
+        (s->resident_chunk != 64 && s->resident_chunk != 128) || s->resident_cap_tiles < 0 ||
+        (s->group_vertices != 0 && s->group_vertices != 6 && s->group_vertices != 7)) {
+        ctx->err = "bad schedule";
+        return RVSEG_ERR_INVALID_ARG;
+    }
+    ctx->sched = *s;
+    return RVSEG_OK;
+}
+
 const char* rvseg_status_string(rvseg_status s) {
     switch (s) {
         case RVSEG_OK: return "ok";
@@ -229,6 +266,7 @@ rvseg_status rvseg_create(const rvseg_params* params, rvseg_ctx** out) {
 
     rvseg_ctx* ctx = new rvseg_ctx();
     ctx->params = p;
+    rvseg_schedule_default(&ctx->sched);
     ctx->feature_length = feature_length_of(p);
     if (!hip_ok(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete ctx;
@@ -376,7 +414,7 @@ rvseg_status rvseg_forest_eval(rvseg_ctx* ctx, const float* X, int32_t P, int32_
     do {
         if (!hip_ok(ctx, hipMemcpyAsync(dX.p, X, (size_t)P * D * sizeof(float), hipMemcpyHostToDevice, ctx->stream), "H2D X")) { rc = RVSEG_ERR_HIP; break; }
         launch_forest_eval(ctx->forest, dX.as<float>(), P, D, dO.as<float>(), ctx->stream);
-        if (!hip_ok(ctx, hipGetLastError(), "forest_eval launch")) { rc = RVSEG_ERR_HIP; break; }
+        if (launch_error_take(ctx) != RVSEG_OK) { rc = RVSEG_ERR_HIP; break; }
         if (!hip_ok(ctx, hipMemcpyAsync(out, dO.p, (size_t)P * S * sizeof(float), hipMemcpyDeviceToHost, ctx->stream), "D2H out")) { rc = RVSEG_ERR_HIP; break; }
         if (!hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync")) { rc = RVSEG_ERR_HIP; break; }
     } while (0);

@@ -34,35 +34,13 @@ struct LatticeDev {
     unsigned *vstart, *vend;     // per vertex [start, end) into the csr arrays
     unsigned* vorder;            // vorder[fstart[f] + k] = k-th longest vertex of frame f (splat launch order)
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
-    // banded splat (counting-sort path): after the scan, bh[wave-block][vertex] is the position of the
-    // vertex's first entry at or after that wave-block, i.e. the vertex-major lists can be cut at any
-    // multiple of CS_PIX points without another sort
+    int group_vertices;          // list-major walk, C = 8 / 9: vertices per block (0 = by the chunk's shape, 6, 7)
+    // counting-sort path: after the scan, bh[wave-block][vertex] is the position of the vertex's first entry at or
+    // after that wave-block, i.e. the vertex-major lists can be cut at any multiple of CS_PIX points without
+    // another sort (the resident band schedule does)
     const unsigned* bh;          // per frame a dense [wbpf][M_f] matrix starting at wbpf * fstart[frame]; null on the radix path
     int wbpf;                    // wave-blocks per frame
-    int n_bands, band_wb;        // bands per frame (1 = whole lists) and wave-blocks per band
     float* norm;                 // per point, pairwise.cpp:55-56
-    const int* skip_if_queue;    // non-null: this launch only runs when the band-major queue could not be built ([0] == 0)
-};
-
-// Band-major work queue of the ordered splat (experimental schedule, RVSEG_SPLAT_QUEUE=1).  Every vertex list is cut
-// at multiples of `band_wb` wave-blocks of 256 points; the pieces of a (frame, band) are sorted by length and packed
-// seven to a group; queue x holds the groups of the frames f = x (mod NQ), band after band.  A piece continues the
-// fp32 chain of its vertex where the previous piece stopped: the running sums travel through `values`, `vprog[v]` is
-// the list position up to which vertex v has been summed.
-struct QueueItem { int v; unsigned k0, k1; unsigned flags; };   // flags: 1 = valid, 2 = first piece of its vertex, 4 = last
-struct SplatQueueDev {
-    QueueItem* items;       // groups of 7 items; queue x starts at group q_base[x]
-    unsigned* grp_cnt;      // [NQ][n_bands * nfq]: groups of (band, frame slot)
-    unsigned* grp_off;      // exclusive scan of grp_cnt inside a queue
-    unsigned* q_total;      // [NQ]
-    unsigned* q_base;       // [NQ]
-    unsigned* head;         // [NQ] tickets of the running launch (zeroed before it)
-    unsigned long long* vacc;   // [m_bound][C <= 16] granules {running sum bits, list position}
-    int* flags;             // [0] queue valid (built without exceeding cap_groups), [1] a dependency wait timed out
-    int band_wb, n_bands, nfq, NQ;
-    unsigned long long* trace;   // optional (RVSEG_SPLAT_QUEUE_TRACE=1): per group {picked, dependencies met, done} in 10 ns ticks + steps
-    int ascending;          // order of a (frame, band)'s pieces inside the queue: shortest first (1) or longest first (0)
-    unsigned cap_groups;
 };
 
 // Band-interleaved resident schedule of the ordered splat ("resident bands").  A frame's
@@ -88,7 +66,7 @@ struct SplatResidentDev {
     unsigned* jb_tile;           // [n_frames][RES_MAXB][n_bands + 1]: first tile of (block, band), relative to the frame
     unsigned* prog;              // [2 scratch slots][n_frames][RES_MAXB]: launch tag << 16 | band reached
     int* flags;                  // [0] frames the planner could not handle, [1] = 1: schedule valid
-    unsigned long long* trace;   // optional (RVSEG_SPLAT_RESIDENT_TRACE=1): per (frame, block) 8 words: start, end, tiles, ticks spent waiting for the pace (10 ns ticks), shader clocks
+    unsigned long long* trace;   // optional (rvseg_schedule.trace): per (frame, block) 8 words: start, end, tiles, ticks spent waiting for the pace (10 ns ticks), shader clocks
     int B, band_wb, n_bands, window;
     int chunk_log2;              // entries per slot and tile: 2^6 or 2^7
     unsigned cap_tiles;
@@ -140,14 +118,12 @@ void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 // own_q: src is the mean-field loop's own Q * norm (finite, non-negative): enables the select-free producer
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q = false,
-                  const SplatQueueDev* queue = nullptr, const SplatResidentDev* resident = nullptr, int slot = 0);
+                  const SplatResidentDev* resident = nullptr, int slot = 0);
 // builds the resident band schedule from the counting-sort table (after launch_lattice_finish)
 void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& r, hipStream_t s);
 // how many blocks of the resident splat kernel fit on the device at once (0: unknown)
 int resident_block_capacity(int chunk);
 int resident_cu_count();
-// builds the band-major queue from the counting-sort table (after launch_lattice_finish)
-void launch_queue_build(const LatticeDev& L, const SplatQueueDev& q, hipStream_t s);
 float* launch_blur(const LatticeDev& L, int C, bool seq, bool reverse, float* a, float* b, hipStream_t s, bool small_blocks = false);
 // out_mode 0: plain, 1: normaliser, 2: inference update (tmp -= (-w) * (sliced * norm))
 void launch_slice(const LatticeDev& L, int C, bool seq, int out_mode, const float* values, float neg_w, float* out,
@@ -159,6 +135,7 @@ struct MfLabels {
     int8_t* labels;
     int mode, unknown, n_layers, layer;
 };
+bool mf_fused_supported(int C);
 bool launch_mf_update(const LatticeDev& L, int C, const float* values, float neg_w, const ValueView& unary, bool negate,
                       const ValueView& Q, bool scale_out, const MfLabels& lab, hipStream_t s);
 void launch_neg_unary(const ValueView& unary, bool negate, int C, int N, float* tmp, long long n_points, hipStream_t s);

@@ -14,9 +14,6 @@ namespace rvseg {
 struct LatticeBufs {
     DevBuf state, tkeys, slot_to_id, counters, vkeys, offsets, bary, nb1, nb2, csr_pw, csr_nrm, vstart, vend, norm;
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_temp, scan_temp, fstart, vorder, block_hist;
-    DevBuf q_items, q_cnt, q_off, q_small, q_vprog, q_trace;   // band-major splat queue (RVSEG_SPLAT_QUEUE=1)
-    SplatQueueDev queue{};
-    bool queue_on = false;
     DevBuf r_desc, r_vl, r_info, r_small, r_verts, r_jb, r_trace;   // resident band schedule of the splat
     SplatResidentDev resident{};
     bool resident_on = false;
@@ -33,21 +30,27 @@ struct CrfState {
     DevBuf val_a, val_b, tmp, q, qn, unary, feat, labels, val_a2, val_b2, tmp2, qn2;
     hipStream_t layer_stream = nullptr;       // the second layer's stream
     hipEvent_t layer_fork = nullptr, layer_join = nullptr;
-    int* h_counters = nullptr;     // pinned: [0] M, [1] overflow, [2] filled of the last build
+    // pinned read-back of a build: [0] M, [1] overflow, [2] filled, [3] frames the splat planner gave up on.
+    // Slot 0 (words 0..3) belongs to the asynchronous frame builds (consumed by crf_frames_status), slot 1 (words 4..7)
+    // to the synchronous entry points -- a cloud or host CRF call on the same context must not overwrite a frame
+    // build's status that nobody has polled yet.
+    int* h_counters = nullptr;
     hipEvent_t counters_ev = nullptr;
     bool counters_pending = false;
+    rvseg_schedule_info info{};    // what the last build ran with (rvseg_last_schedule)
+    bool info_async = false;       // info.vertices / planner_fallback still travel with the pending frame-build status
 };
 
 static rvseg_status crf_state(rvseg_ctx* ctx, Pipeline* im, CrfState** out) {
     if (!im->crf) {
         CrfState* cs = new CrfState();
-        if (!hip_ok(ctx, hipHostMalloc((void**)&cs->h_counters, 4 * sizeof(int), hipHostMallocDefault), "hipHostMalloc(counters)") ||
+        if (!hip_ok(ctx, hipHostMalloc((void**)&cs->h_counters, 8 * sizeof(int), hipHostMallocDefault), "hipHostMalloc(counters)") ||
             !hip_ok(ctx, hipEventCreateWithFlags(&cs->counters_ev, hipEventDisableTiming), "hipEventCreate(counters)")) {
             if (cs->h_counters) (void)hipHostFree(cs->h_counters);
             delete cs;
             return RVSEG_ERR_HIP;
         }
-        cs->h_counters[0] = cs->h_counters[1] = cs->h_counters[2] = cs->h_counters[3] = 0;
+        for (int i = 0; i < 8; i++) cs->h_counters[i] = 0;
         im->crf = cs;
     }
     *out = im->crf;
@@ -58,7 +61,6 @@ static void lattice_free(LatticeBufs& b) {
     DevBuf* all[] = {&b.state, &b.tkeys, &b.slot_to_id, &b.counters, &b.vkeys, &b.offsets, &b.bary, &b.nb1, &b.nb2,
                      &b.csr_pw, &b.csr_nrm, &b.vstart, &b.vend, &b.norm, &b.keys_in, &b.keys_out, &b.vals_in,
                      &b.vals_out, &b.sort_temp, &b.scan_temp, &b.fstart, &b.vorder, &b.block_hist,
-                     &b.q_items, &b.q_cnt, &b.q_off, &b.q_small, &b.q_vprog, &b.q_trace,
                      &b.r_desc, &b.r_vl, &b.r_info, &b.r_small, &b.r_verts, &b.r_jb, &b.r_trace};
     for (DevBuf* x : all) dev_free(*x);
 }
@@ -99,6 +101,14 @@ static int capacity_log2_per_frame(const rvseg_ctx* ctx, int Npad, int d, bool s
 static bool capacity_is_worst_case(const rvseg_ctx* ctx, int N, int d) {
     const int Npad = (N + 3) / 4 * 4;
     return capacity_log2_per_frame(ctx, Npad, d, false) == capacity_log2_per_frame(ctx, Npad, d, true);
+}
+
+// Does the resident band schedule pay for a chunk of this shape?  It wins where the list-major walk is bound by the
+// bytes it re-reads (many frames: 12 % faster at 64 frames of 640x480, 10 % at 16 frames of 1280x960, equal at 32 frames of
+// 640x480) and loses where the longest chain of one frame sets the time (a single frame, a cloud).  Both are functions
+// of the points per chunk and of the frame count, known on the host before the build is enqueued.
+static bool resident_pays(int n_frames, int N) {
+    return n_frames >= 2 && (long long)n_frames * N >= 12000000ll;
 }
 
 static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe) {
@@ -163,111 +173,63 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.temp = b.sort_temp.p; b.sb.temp_bytes = temp; b.sb.key_bits = key_bits;
     b.sb.scan_temp = b.scan_temp.p; b.sb.scan_temp_bytes = stemp;
     b.sb.block_hist = nullptr;
-    L.bh = nullptr; L.wbpf = 0; L.n_bands = 1; L.band_wb = 0;
+    L.bh = nullptr; L.wbpf = 0;
+    L.group_vertices = ctx->sched.group_vertices;
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
         b.sb.block_hist = b.block_hist.as<unsigned>();
-        {
-            const int pixb = csr_pix_per_block();
-            L.bh = b.sb.block_hist;
-            L.wbpf = (N + pixb - 1) / pixb;
-            const char* be = std::getenv("RVSEG_SPLAT_BANDS");
-            int nb = be ? std::atoi(be) : 1;
-            nb = nb < 1 ? 1 : (nb > L.wbpf ? L.wbpf : nb);
-            L.band_wb = (L.wbpf + nb - 1) / nb;
-            L.n_bands = (L.wbpf + L.band_wb - 1) / L.band_wb;
-        }
+        L.bh = b.sb.block_hist;
+        L.wbpf = (N + csr_pix_per_block() - 1) / csr_pix_per_block();
     }
     b.n_entries = E; b.n_points = P;
     b.built = false;
-    // experimental band-major queue schedule of the splat
-    const int queue_env = std::getenv("RVSEG_SPLAT_QUEUE") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE")) : 0;
-    b.queue_on = false;
-    if (queue_env && L.bh && d == 6) {
-        const int band_env = std::getenv("RVSEG_SPLAT_QUEUE_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_BAND")) : 16;
-        SplatQueueDev& q = b.queue;
-        q.band_wb = band_env < 1 ? 1 : band_env;
-        const int asc_env = std::getenv("RVSEG_SPLAT_QUEUE_ASC") ? std::atoi(std::getenv("RVSEG_SPLAT_QUEUE_ASC")) : 0;
-        q.ascending = asc_env;
-        q.n_bands = (L.wbpf + q.band_wb - 1) / q.band_wb;
-        q.NQ = L.n_groups;
-        q.nfq = (n_frames + q.NQ - 1) / q.NQ;
-        q.cap_groups = (unsigned)std::min<unsigned long long>((unsigned long long)n_frames * q.n_bands * 64ull, 1ull << 24);
-        const size_t cells = (size_t)q.NQ * q.n_bands * q.nfq;
-        if ((st = dev_reserve(ctx, b.q_items, (size_t)q.cap_groups * 7 * sizeof(QueueItem))) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, b.q_cnt, cells * 4)) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, b.q_off, cells * 4)) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, b.q_small, 4 * 64 * 4)) != RVSEG_OK) return st;
-        if ((st = dev_reserve(ctx, b.q_vprog, (size_t)m_bound * 16 * 8)) != RVSEG_OK) return st;
-        q.items = b.q_items.as<QueueItem>();
-        q.grp_cnt = b.q_cnt.as<unsigned>(); q.grp_off = b.q_off.as<unsigned>();
-        q.q_total = b.q_small.as<unsigned>(); q.q_base = q.q_total + 64; q.head = q.q_total + 128;
-        q.flags = reinterpret_cast<int*>(q.q_total + 192);
-        q.vacc = b.q_vprog.as<unsigned long long>();
-        q.trace = nullptr;
-        if (std::getenv("RVSEG_SPLAT_QUEUE_TRACE")) {
-            if ((st = dev_reserve(ctx, b.q_trace, (size_t)q.cap_groups * 32)) != RVSEG_OK) return st;
-            q.trace = b.q_trace.as<unsigned long long>();
-        }
-        b.queue_on = true;
-    }
     // Resident band schedule of the mean-field splat: chunks of many frames, whose splat is
     // bound by the bytes the list-major walk re-reads.  All n_frames x B blocks have to be on the chip together.
     b.resident_on = false;
     {
-        const int res_env = std::getenv("RVSEG_SPLAT_RESIDENT") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT")) : 1;
-        const int b_env = std::getenv("RVSEG_SPLAT_RESIDENT_B") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_B")) : 0;
-        const int band_env = std::getenv("RVSEG_SPLAT_RESIDENT_BAND") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_BAND")) : 16;
-        const int win_env = std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_WINDOW")) : -1;   // measured: pacing costs more than its locality saves (the kernel is issue bound)
-        // Worth it where the list-major walk is bound by the bytes it re-reads: measured equal at 32 frames of 640x480
-        // (9.8 M points per chunk), 12 % faster at 64, 10 % faster at 16 frames of 1280x960 (19.7 M); slower on a single
-        // frame or cloud, whose longest chain sets the time (RVSEG_SPLAT_RESIDENT=2: always, for tests)
-        const bool big_enough = res_env > 1 || (n_frames >= 2 && (long long)n_frames * N >= 12000000ll);
-        const int chunk_env = std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK") ? std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CHUNK")) : 128;
-        const int chunk = chunk_env == 64 ? 64 : 128;
+        const rvseg_schedule& sc = ctx->sched;
+        // Worth it where the list-major walk is bound by the bytes it re-reads rather than by its longest chain
+        // ("where it pays"): see resident_pays().  sched.splat = 2 forces it, 1 forbids it.
+        const bool wanted = sc.splat == 2 || (sc.splat == 0 && resident_pays(n_frames, N));
+        const int chunk = sc.resident_chunk == 64 ? 64 : 128;
         const int capacity = resident_block_capacity(chunk);
         // one block per CU measured best (the tile loop is bound by its own barrier-coupled latencies, a second block on
         // the CU slows both): B = CUs / frames, at least 2, at most 12
-        int B = b_env > 0 ? b_env : (n_frames > 0 ? resident_cu_count() / n_frames : 0);
-        if (b_env <= 0) B = B < 2 ? 2 : (B > 12 ? 12 : B);
+        int B = sc.resident_blocks > 0 ? sc.resident_blocks : (n_frames > 0 ? resident_cu_count() / n_frames : 0);
+        if (sc.resident_blocks <= 0) B = B < 2 ? 2 : (B > 12 ? 12 : B);
         B = B > RES_MAXB ? RES_MAXB : B;
-        if (res_env && !b.queue_on && L.bh && d == 6 && big_enough && B >= 2 && (long long)n_frames * B <= capacity &&
+        if (wanted && L.bh && d == 6 && B >= 2 && (long long)n_frames * B <= capacity &&
             7ll * N < (1ll << 24) && (long long)L.wbpf <= 32ll * RES_MAX_BANDS) {   // (bands stay under 64 wave-blocks: chunk counts fit 8 bits)
             SplatResidentDev& R = b.resident;
             R.B = B;
-            R.band_wb = band_env < 1 ? 1 : (band_env > 32 ? 32 : band_env);
+            R.band_wb = sc.resident_band < 1 ? 1 : (sc.resident_band > 32 ? 32 : sc.resident_band);
             R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb;
             while (R.n_bands > RES_MAX_BANDS) { R.band_wb *= 2; R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb; }
-            R.window = win_env;
+            R.window = sc.resident_window;
             R.chunk_log2 = chunk == 128 ? 7 : 6;
             R.cap_tiles = (unsigned)(N / 8 + 1024);
-            if (std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES")) {   // (tests shrink it to see the planner give up)
-                const int ct = std::atoi(std::getenv("RVSEG_SPLAT_RESIDENT_CAP_TILES"));
-                if (ct > 0 && (unsigned)ct < R.cap_tiles) R.cap_tiles = (unsigned)ct;
+            if (sc.resident_cap_tiles > 0 && (unsigned)sc.resident_cap_tiles < R.cap_tiles) R.cap_tiles = (unsigned)sc.resident_cap_tiles;
+            const size_t small = (16 + (size_t)n_frames * (RES_MAXB + 1) + (size_t)n_frames * RES_MAXB + 2 * (size_t)n_frames * RES_MAXB) * 4;
+            if ((st = dev_reserve(ctx, b.r_desc, (size_t)n_frames * 7 * R.cap_tiles * 4)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, b.r_vl, (size_t)n_frames * 7 * R.cap_tiles * 2)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, b.r_info, (size_t)n_frames * R.cap_tiles * 4)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, b.r_small, small)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, b.r_verts, (size_t)n_frames * RES_MAXB * RES_MAX_OWNV * 2)) != RVSEG_OK) return st;
+            if ((st = dev_reserve(ctx, b.r_jb, (size_t)n_frames * RES_MAXB * (R.n_bands + 1) * 4)) != RVSEG_OK) return st;
+            R.tdesc = b.r_desc.as<unsigned>(); R.tvl = b.r_vl.as<unsigned short>(); R.tinfo = b.r_info.as<unsigned>();
+            unsigned* sm = b.r_small.as<unsigned>();
+            R.flags = reinterpret_cast<int*>(sm); sm += 16;
+            R.blk_tile0 = sm; sm += (size_t)n_frames * (RES_MAXB + 1);
+            R.blk_nown = sm; sm += (size_t)n_frames * RES_MAXB;
+            R.prog = sm;
+            R.blk_verts = b.r_verts.as<unsigned short>();
+            R.jb_tile = b.r_jb.as<unsigned>();
+            R.trace = nullptr;
+            if (sc.trace) {
+                if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 64)) != RVSEG_OK) return st;
+                R.trace = b.r_trace.as<unsigned long long>();
             }
-            {
-                const size_t small = (16 + (size_t)n_frames * (RES_MAXB + 1) + (size_t)n_frames * RES_MAXB + 2 * (size_t)n_frames * RES_MAXB) * 4;
-                if ((st = dev_reserve(ctx, b.r_desc, (size_t)n_frames * 7 * R.cap_tiles * 4)) != RVSEG_OK) return st;
-                if ((st = dev_reserve(ctx, b.r_vl, (size_t)n_frames * 7 * R.cap_tiles * 2)) != RVSEG_OK) return st;
-                if ((st = dev_reserve(ctx, b.r_info, (size_t)n_frames * R.cap_tiles * 4)) != RVSEG_OK) return st;
-                if ((st = dev_reserve(ctx, b.r_small, small)) != RVSEG_OK) return st;
-                if ((st = dev_reserve(ctx, b.r_verts, (size_t)n_frames * RES_MAXB * RES_MAX_OWNV * 2)) != RVSEG_OK) return st;
-                if ((st = dev_reserve(ctx, b.r_jb, (size_t)n_frames * RES_MAXB * (R.n_bands + 1) * 4)) != RVSEG_OK) return st;
-                R.tdesc = b.r_desc.as<unsigned>(); R.tvl = b.r_vl.as<unsigned short>(); R.tinfo = b.r_info.as<unsigned>();
-                unsigned* sm = b.r_small.as<unsigned>();
-                R.flags = reinterpret_cast<int*>(sm); sm += 16;
-                R.blk_tile0 = sm; sm += (size_t)n_frames * (RES_MAXB + 1);
-                R.blk_nown = sm; sm += (size_t)n_frames * RES_MAXB;
-                R.prog = sm;
-                R.blk_verts = b.r_verts.as<unsigned short>();
-                R.jb_tile = b.r_jb.as<unsigned>();
-                R.trace = nullptr;
-                if (std::getenv("RVSEG_SPLAT_RESIDENT_TRACE")) {
-                    if ((st = dev_reserve(ctx, b.r_trace, (size_t)n_frames * RES_MAXB * 64)) != RVSEG_OK) return st;
-                    R.trace = b.r_trace.as<unsigned long long>();
-                }
-                b.resident_on = true;
-            }
+            b.resident_on = true;
         }
     }
     return RVSEG_OK;
@@ -298,7 +260,7 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
     RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
     RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
-    const bool trace = std::getenv("RVSEG_TRACE") != nullptr;
+    const bool trace = ctx->sched.trace >= 2;
     auto tr = [&](const char* what) {
         if (!trace) return;
         hipError_t e = hipStreamSynchronize(s);
@@ -309,12 +271,6 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     tr("points");
     launch_lattice_finish(L, b.sb, b.n_entries, s);
     tr("finish");
-    if (b.queue_on) {
-        RV_HIP(ctx, hipMemsetAsync(b.q_small.p, 0, 4 * 64 * 4, s));
-        RV_HIP(ctx, hipMemsetAsync(b.q_vprog.p, 0xFF, (size_t)L.m_bound * 16 * 8, s));
-        launch_queue_build(L, b.queue, s);
-        tr("queue");
-    }
     rvseg_status st;
     bool plan_forked = false;
     if (b.resident_on) {
@@ -337,16 +293,42 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     launch_slice(L, 1, true, 1, blurred, 0.f, L.norm, b.n_points, s);
     tr("normaliser");
     if (plan_forked) RV_HIP(ctx, hipStreamWaitEvent(s, cs->layer_join, 0));
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     b.built = true;
+    rvseg_schedule_info& inf = cs->info;
+    inf.splat = b.resident_on ? 2 : 1;
+    inf.planner_fallback = -1;
+    inf.csr_path = L.bh ? 1 : 2;
+    inf.n_frames = L.n_frames;
+    inf.points_per_frame = L.N;
+    inf.vertices = -1;
+    inf.resident_blocks = b.resident_on ? b.resident.B : 0;
+    inf.resident_band = b.resident_on ? b.resident.band_wb : 0;
+    inf.resident_chunk = b.resident_on ? (1 << b.resident.chunk_log2) : 0;
+    inf.capacity_log2 = (int)L.cap_f_log2;
+    return RVSEG_OK;
+}
+
+// enqueues the read-back of a build's counters (+ the planner's flag) into pinned slot `slot` (0: async frame builds,
+// 1: synchronous entry points)
+static rvseg_status counters_readback(rvseg_ctx* ctx, CrfState* cs, const LatticeBufs& b, int slot, hipStream_t s) {
+    int* h = cs->h_counters + 4 * slot;
+    RV_HIP(ctx, hipMemcpyAsync(h, b.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (b.resident_on) RV_HIP(ctx, hipMemcpyAsync(h + 3, b.resident.flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    else h[3] = 0;   // (host write; no copy of this build touches the word)
     return RVSEG_OK;
 }
 
 // synchronous read of the build counters (host entry points)
 static rvseg_status lattice_counters(rvseg_ctx* ctx, CrfState* cs, const LatticeBufs& b, hipStream_t s, int out[3]) {
-    RV_HIP(ctx, hipMemcpyAsync(cs->h_counters, b.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    rvseg_status st = counters_readback(ctx, cs, b, 1, s);
+    if (st != RVSEG_OK) return st;
     RV_HIP(ctx, hipStreamSynchronize(s));
-    out[0] = cs->h_counters[0]; out[1] = cs->h_counters[1]; out[2] = cs->h_counters[2];
+    const int* h = cs->h_counters + 4;
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    cs->info.vertices = h[0];
+    cs->info.planner_fallback = h[3];
+    cs->info_async = false;
     return RVSEG_OK;
 }
 
@@ -359,6 +341,26 @@ static void filter_into(rvseg_ctx* ctx, const LatticeBufs& b, CrfState* cs, cons
     float* blurred = launch_blur(b.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
     timer_mark(ctx, "slice", s);
     launch_slice(b.dev, C, seq, 2, blurred, -w, tmp, b.n_points, s);
+}
+
+// per-entry copy of the normaliser for the unfused splat (MODE 1); filled once per lattice
+static rvseg_status ensure_csr_nrm(rvseg_ctx* ctx, LatticeBufs& b, hipStream_t s) {
+    if (b.has_csr_nrm) return RVSEG_OK;
+    rvseg_status st = dev_reserve(ctx, b.csr_nrm, (size_t)b.n_entries * 4);
+    if (st != RVSEG_OK) return st;
+    b.dev.csr_nrm = b.csr_nrm.as<float>();
+    launch_csr_norm(b.dev, b.n_entries, s);
+    b.has_csr_nrm = true;
+    return RVSEG_OK;
+}
+
+// Layers that run side by side on two streams share the lattice's csr_nrm table: when any of them takes the unfused
+// path (no fused instantiation for its class count) the table is filled on the PARENT stream before the fork, so the
+// stream that did not enqueue the fill cannot read it early.
+static rvseg_status csr_nrm_before_fork(rvseg_ctx* ctx, CrfState* cs, int n_layers, const int* class_counts, int iterations, hipStream_t s) {
+    for (int l = 0; l < n_layers; l++)
+        if (!(iterations > 0 && mf_fused_supported(class_counts[l]))) return ensure_csr_nrm(ctx, cs->lat[0], s);
+    return RVSEG_OK;
 }
 
 // DenseCRF::inference (densecrf.cpp:115-131)
@@ -402,14 +404,8 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
     }
     if (!fused) {
         // the general path scales by the normaliser inside the splat: per-entry copy of norm
-        for (int k = 0; k < n_kernels; k++) {
-            LatticeBufs& b = cs->lat[k];
-            if (b.has_csr_nrm) continue;
-            if ((st = dev_reserve(ctx, b.csr_nrm, (size_t)b.n_entries * 4)) != RVSEG_OK) return st;
-            b.dev.csr_nrm = b.csr_nrm.as<float>();
-            launch_csr_norm(b.dev, b.n_entries, s);
-            b.has_csr_nrm = true;
-        }
+        for (int k = 0; k < n_kernels; k++)
+            if ((st = ensure_csr_nrm(ctx, cs->lat[k], s)) != RVSEG_OK) return st;
     }
     for (int it = 0; it < iterations; it++) {
         if (n_kernels == 1) {
@@ -417,8 +413,7 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
             const LatticeBufs& b = cs->lat[0];
             const bool seq = C <= 2;
             mark("splat");
-            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused, (b.queue_on && slot == 0) ? &b.queue : nullptr,
-                         b.resident_on ? &b.resident : nullptr, slot);
+            launch_splat(b.dev, fused ? Qs : Q, C, fused ? 0 : 1, b_va.as<float>(), s, fused, b.resident_on ? &b.resident : nullptr, slot);
             mark("blur");
             float* blurred = launch_blur(b.dev, C, seq, false, b_va.as<float>(), b_vb.as<float>(), s);
             if (fused) {
@@ -443,7 +438,7 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
         mark("softmax");
         launch_softmax(tmp, C, N, Q, n_points, s);
     }
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -452,8 +447,7 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
 // has few frames (a cloud, a 1280x960 chunk), so odd layers run on a second stream beside the even ones.
 static rvseg_status layer_stream_fork(rvseg_ctx* ctx, CrfState* cs, hipStream_t s, int n_layers, hipStream_t* s2) {
     *s2 = s;
-    static const bool serial = std::getenv("RVSEG_NO_LAYER_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_LAYER_OVERLAP")) != 0;
-    if (n_layers < 2 || serial) return RVSEG_OK;
+    if (n_layers < 2 || !ctx->sched.overlap_layers) return RVSEG_OK;
     rvseg_status st = second_stream(ctx, cs);
     if (st != RVSEG_OK) return st;
     RV_HIP(ctx, hipEventRecord(cs->layer_fork, s));
@@ -483,6 +477,11 @@ rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait) {
         RV_HIP(ctx, e);
     }
     cs->counters_pending = false;
+    if (cs->info_async) {   // no other lattice has been built on this context since
+        cs->info.vertices = cs->h_counters[0];
+        cs->info.planner_fallback = cs->h_counters[3];
+        cs->info_async = false;
+    }
     if (cs->h_counters[1]) {
         const FrameGeom& g = im->geom;
         const bool was_worst = capacity_is_worst_case(ctx, g.W * g.H, 6);
@@ -518,9 +517,10 @@ rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     fs.mode = 1; fs.cloud = im->cloud.as<float4>(); fs.rgb = d_rgb;
     fs.xyz_kernel = p.dcrf_xyz_kernel; fs.rgb_kernel = p.dcrf_rgb_kernel;
     if ((st = lattice_build(ctx, cs, lb, fs, s)) != RVSEG_OK) return st;
-    RV_HIP(ctx, hipMemcpyAsync(cs->h_counters, lb.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if ((st = counters_readback(ctx, cs, lb, 0, s)) != RVSEG_OK) return st;
     RV_HIP(ctx, hipEventRecord(cs->counters_ev, s));
     cs->counters_pending = true;
+    cs->info_async = true;
     return RVSEG_OK;
 }
 
@@ -544,6 +544,7 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
     const float w = p.dcrf_kernel_weight;
     bool all_labelled = true;   // the last fused update of every layer wrote its labels
     hipStream_t s2;
+    if ((st = csr_nrm_before_fork(ctx, cs, f.n_layers, f.class_counts, p.dcrf_iterations, s)) != RVSEG_OK) return st;
     if ((st = layer_stream_fork(ctx, cs, s, f.n_layers, &s2)) != RVSEG_OK) return st;
     for (int l = 0; l < f.n_layers; l++) {
         const int C = f.class_counts[l];
@@ -607,6 +608,7 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
     // marginals of even / odd layers in two halves of cs->q (the odd layers run on the second stream)
     if ((st = dev_reserve(ctx, cs->q, (size_t)N * cmax * 4 * 2)) != RVSEG_OK) return st;
     hipStream_t s2;
+    if ((st = csr_nrm_before_fork(ctx, cs, n_layers, class_counts, iterations, s)) != RVSEG_OK) return st;
     if ((st = layer_stream_fork(ctx, cs, s, n_layers, &s2)) != RVSEG_OK) return st;
     size_t prefix = 0;
     for (int l = 0; l < n_layers; l++) {
@@ -628,7 +630,7 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
         prefix += C;
     }
     if ((st = layer_stream_join(ctx, cs, s, s2)) != RVSEG_OK) return st;
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -729,7 +731,7 @@ rvseg_status rvseg_crf_infer_device(rvseg_ctx* ctx, int32_t N, int32_t C, int32_
         launch_labels(q, (size_t)N, C, label_mode, unknown_label, d_map_out, s);
     }
     timer_mark(ctx, "end", s);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -820,22 +822,14 @@ extern "C" rvseg_status rvseg_debug_resident(rvseg_ctx* ctx, void* trace_out, si
     return RVSEG_OK;
 }
 
-// debug (not in rvseg.h): the queue of the frame path's last lattice: items (16 B each), per-cell group offsets, trace
-rvseg_status rvseg_debug_queue(rvseg_ctx* ctx, void* items_out, size_t items_cap, unsigned* n_groups_total, unsigned* q_base8, unsigned* q_total8,
-                               unsigned long long* trace_out, int* meta /* band_wb, n_bands, nfq, NQ */) {
-    if (!ctx || !ctx->impl) return RVSEG_ERR_INVALID_ARG;
+rvseg_status rvseg_last_schedule(rvseg_ctx* ctx, rvseg_schedule_info* out) {
+    if (!ctx || !out) return RVSEG_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->planner_fallback = -1;
+    out->vertices = -1;
+    if (!ctx->impl) return RVSEG_OK;
     Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
-    if (!im->crf || im->crf->lat.empty() || !im->crf->lat[0].queue_on) return RVSEG_ERR_INVALID_ARG;
-    LatticeBufs& b = im->crf->lat[0];
-    RV_HIP(ctx, hipDeviceSynchronize());
-    unsigned small[256];
-    RV_HIP(ctx, hipMemcpy(small, b.q_small.p, sizeof(small), hipMemcpyDeviceToHost));
-    unsigned tot = 0;
-    for (int x = 0; x < b.queue.NQ; x++) { q_base8[x] = small[64 + x]; q_total8[x] = small[x]; tot += small[x]; }
-    *n_groups_total = tot;
-    meta[0] = b.queue.band_wb; meta[1] = b.queue.n_bands; meta[2] = b.queue.nfq; meta[3] = b.queue.NQ;
-    if (items_out && items_cap >= (size_t)tot * 7 * 16) RV_HIP(ctx, hipMemcpy(items_out, b.q_items.p, (size_t)tot * 7 * 16, hipMemcpyDeviceToHost));
-    if (trace_out && b.queue.trace) RV_HIP(ctx, hipMemcpy(trace_out, b.q_trace.p, (size_t)tot * 32, hipMemcpyDeviceToHost));
+    if (im->crf) *out = im->crf->info;
     return RVSEG_OK;
 }
 
@@ -858,7 +852,7 @@ rvseg_status rvseg_lattice_filter(rvseg_ctx* ctx, const float* in, int32_t C, fl
     launch_splat(lb.dev, V, C, 0, cs->val_a.as<float>(), s);
     float* blurred = launch_blur(lb.dev, C, seq, false, cs->val_a.as<float>(), cs->val_b.as<float>(), s);
     launch_slice(lb.dev, C, seq, 0, blurred, 0.f, cs->tmp.as<float>(), N, s);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     RV_HIP(ctx, hipMemcpyAsync(out, cs->tmp.p, tot * 4, hipMemcpyDeviceToHost, s));
     RV_HIP(ctx, hipStreamSynchronize(s));
     return RVSEG_OK;

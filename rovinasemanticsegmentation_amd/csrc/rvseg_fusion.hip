@@ -191,7 +191,7 @@ static rvseg_status fuse_device(rvseg_ctx* ctx, FusionState* fs, const FusionLay
     const long long threads = (long long)cloud_size * S;
     fusion_gather_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>(
         fl, cloud_size, (unsigned)pixels, fs->vout.as<unsigned>(), fs->start.as<unsigned>(), fs->end.as<unsigned>(), d_posteriors, d_unaries);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     RV_HIP(ctx, hipMemcpyAsync(fs->h_bad, fs->bad.p, 4, hipMemcpyDeviceToHost, s));
     RV_HIP(ctx, hipEventRecord(fs->bad_ev, s));
     fs->bad_pending = true;
@@ -271,7 +271,7 @@ extern "C" rvseg_status rvseg_cloud_features_device(rvseg_ctx* ctx, int32_t N, c
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     cloud_features_kernel<<<dim3((unsigned)(((long long)N + 255) / 256)), dim3(256), 0, s>>>(d_xyz, d_rgb, ctx->params.dcrf_xyz_kernel,
                                                                                              ctx->params.dcrf_rgb_kernel, d_features_out, N);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -286,7 +286,7 @@ extern "C" rvseg_status rvseg_label_values_device(rvseg_ctx* ctx, const float* d
     RV_HIP(ctx, hipSetDevice(ctx->params.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     launch_labels(d_values, (size_t)N, C, label_mode, unknown_label, d_labels_out, s);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -329,7 +329,7 @@ extern "C" rvseg_status rvseg_process_map_device(rvseg_ctx* ctx, int32_t n_image
         timer_mark(ctx, "cloud_features", s);
         cloud_features_kernel<<<dim3((unsigned)(((long long)cloud_size + 255) / 256)), dim3(256), 0, s>>>(
             d_cloud_xyz, d_cloud_rgb, p.dcrf_xyz_kernel, p.dcrf_rgb_kernel, fs->map_feat.as<float>(), cloud_size);
-        RV_HIP(ctx, hipGetLastError());
+        RV_LAUNCH_OK(ctx);
         // one lattice serves every layer (the reference builds an identical one per layer, :639-644)
         if ((st = crf_cloud_layers(ctx, cloud_size, f.n_layers, f.class_counts, un, fs->map_feat.as<float>(), p.dcrf_kernel_weight,
                                    p.dcrf_iterations, RVSEG_LABEL_CRF, p.unknown_label, d_labels_out, s)) != RVSEG_OK) return st;
@@ -338,7 +338,7 @@ extern "C" rvseg_status rvseg_process_map_device(rvseg_ctx* ctx, int32_t n_image
         for (int l = 0; l < f.n_layers; l++)
             launch_labels(un + (size_t)cloud_size * fl.prefix[l], (size_t)cloud_size, f.class_counts[l], RVSEG_LABEL_NOCRF, p.unknown_label[l],
                           d_labels_out + (size_t)l * cloud_size, s);
-        RV_HIP(ctx, hipGetLastError());
+        RV_LAUNCH_OK(ctx);
     }
     timer_mark(ctx, "end", s);
     return RVSEG_OK;
@@ -364,7 +364,7 @@ extern "C" rvseg_status rvseg_label_values(rvseg_ctx* ctx, const float* values, 
 #define RV_TRY(call) if (!hip_ok(ctx, (call), #call)) { rc = RVSEG_ERR_HIP; break; }
         RV_TRY(hipMemcpyAsync(d_v.p, values, (size_t)N * C * 4, hipMemcpyHostToDevice, s));
         launch_labels(d_v.as<float>(), (size_t)N, C, label_mode, unknown_label, d_l.as<int8_t>(), s);
-        RV_TRY(hipGetLastError());
+        if ((rc = launch_error_take(ctx)) != RVSEG_OK) break;
         RV_TRY(hipMemcpyAsync(labels_out, d_l.p, (size_t)N, hipMemcpyDeviceToHost, s));
         RV_TRY(hipStreamSynchronize(s));
 #undef RV_TRY

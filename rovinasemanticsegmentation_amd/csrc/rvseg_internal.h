@@ -59,6 +59,7 @@ struct StageTimer {
 
 struct rvseg_ctx {
     rvseg_params params{};
+    rvseg_schedule sched{};        // rvseg_set_schedule; defaults from rvseg_schedule_default
     int feature_length = 0;
     std::string err;
     rvseg::ForestModel host_forest;
@@ -82,6 +83,18 @@ bool hip_ok(rvseg_ctx* ctx, hipError_t e, const char* what);
 #define RV_HIP(ctx, call)                                           \
     do {                                                            \
         if (!::rvseg::hip_ok((ctx), (call), #call)) return RVSEG_ERR_HIP; \
+    } while (0)
+
+// Kernel launches happen inside void launch_* helpers.  Every launch group ends with RV_LAUNCHED(name): a launch the
+// runtime refused (bad grid, too much LDS, ...) is parked per thread with the kernel's name -- the first one wins -- and
+// the orchestration turns it into RVSEG_ERR_HIP with launch_error_take(), so no launch fails silently.
+void launch_check(const char* what);
+rvseg_status launch_error_take(rvseg_ctx* ctx);
+#define RV_LAUNCHED(name) ::rvseg::launch_check(name)
+#define RV_LAUNCH_OK(ctx)                                               \
+    do {                                                                \
+        const rvseg_status st__ = ::rvseg::launch_error_take(ctx);      \
+        if (st__ != RVSEG_OK) return st__;                              \
     } while (0)
 
 rvseg_status dev_alloc(rvseg_ctx* ctx, DevBuf& b, size_t bytes);

@@ -217,18 +217,17 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     timer_mark(ctx, "prep", s);
     launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
                 need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s);
-    static const bool no_overlap = std::getenv("RVSEG_NO_OVERLAP") && std::atoi(std::getenv("RVSEG_NO_OVERLAP")) != 0;
     bool forked = false;
-    if (p.use_dense_crf && !no_overlap) {
+    if (p.use_dense_crf && ctx->sched.overlap_build) {
         // fork: the lattice build runs on the side stream while this stream extracts features and walks the forest
         if (!im->side) {
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
             // priority of the build stream.  Round 1 (build = the longer branch) measured the highest priority ahead,
             // 13.85 vs 13.98 ms per step; since the feature branch is the longer one (5.2 vs 3.6 ms) the lowest is, by
-            // a little: 13.31 / 13.33 vs 13.37 / 13.42 ms (RVSEG_SIDE_PRIO_HIGH=1 restores the old choice)
-            static const int side_high = std::getenv("RVSEG_SIDE_PRIO_HIGH") ? std::atoi(std::getenv("RVSEG_SIDE_PRIO_HIGH")) : 0;
-            RV_HIP(ctx, hipStreamCreateWithPriority(&im->side, hipStreamNonBlocking, side_high ? prio_hi : prio_lo));
+            // a little: 13.31 / 13.33 vs 13.37 / 13.42 ms (rvseg_schedule.build_priority_high restores the old choice;
+            // it is read when the stream is created, i.e. before the first frame call of the context)
+            RV_HIP(ctx, hipStreamCreateWithPriority(&im->side, hipStreamNonBlocking, ctx->sched.build_priority_high ? prio_hi : prio_lo));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_fork, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_join, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreate(&ctx->timer.side0));
@@ -269,7 +268,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
         launch_labels_frames(post, n, (int)npix, f, p.label_mode, p.unknown_label, d_labels, s);
     }
     timer_mark(ctx, "end", s);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     return RVSEG_OK;
 }
 
@@ -504,7 +503,7 @@ rvseg_status rvseg_extract_features(rvseg_ctx* ctx, const uint8_t* rgb, const ui
     DeviceForest none = ctx->forest;
     launch_rf_frames(g, none, im->resize_rows.as<ResizeRow>(), im->lab.as<uint32_t>(), im->in_depth.as<uint16_t>(),
                      im->cloud.as<float4>(), im->nfeat.as<float>(), nullptr, im->dump.as<float>(), im->valid.as<uint8_t>(), 1, s);
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
     std::vector<float> dump((size_t)P * g.D);
     std::vector<uint8_t> valid((size_t)P);
     RV_HIP(ctx, hipMemcpyAsync(dump.data(), im->dump.p, dump.size() * 4, hipMemcpyDeviceToHost, s));

@@ -316,7 +316,7 @@ rvseg_status rvseg_forest_train(rvseg_ctx* ctx, const float* X, int32_t P, int32
     RV_HIP(ctx, hipMemcpyAsync(bin_lo.data(), dBinLo, bin_lo.size() * 4, hipMemcpyDeviceToHost, s));
     RV_HIP(ctx, hipMemcpyAsync(bin_hi.data(), dBinHi, bin_hi.size() * 4, hipMemcpyDeviceToHost, s));
     RV_HIP(ctx, hipStreamSynchronize(s));
-    RV_HIP(ctx, hipGetLastError());
+    RV_LAUNCH_OK(ctx);
 
     // inverted class frequencies over the whole set (data.h:346-370): freq[c] = size / count_c, in float
     std::vector<std::vector<float>> freq(n_layers);
@@ -385,7 +385,7 @@ rvseg_status rvseg_forest_train(rvseg_ctx* ctx, const float* X, int32_t P, int32
                 train_best_cut_kernel<<<dim3((unsigned)(S * K)), dim3(TR_BINS), 0, s>>>(K, dHist, dCut);
                 RV_HIP(ctx, hipMemcpyAsync(cuts.data(), dCut, (size_t)S * K * sizeof(CutResult), hipMemcpyDeviceToHost, s));
                 RV_HIP(ctx, hipStreamSynchronize(s));
-                RV_HIP(ctx, hipGetLastError());
+                RV_LAUNCH_OK(ctx);
                 for (int q = 0; q < S; q++) {
                     const int node = frontier[base + q];
                     const CutResult& first = cuts[(size_t)q * K];
@@ -425,7 +425,7 @@ rvseg_status rvseg_forest_train(rvseg_ctx* ctx, const float* X, int32_t P, int32
                 RV_HIP(ctx, hipMemcpyAsync(dSL, split_left.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
                 train_route_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(dX, P, D, dNode, dSF, dST, dSL);
                 RV_HIP(ctx, hipStreamSynchronize(s));
-                RV_HIP(ctx, hipGetLastError());
+                RV_LAUNCH_OK(ctx);
             }
             frontier.swap(next_frontier);
         }
@@ -438,7 +438,7 @@ rvseg_status rvseg_forest_train(rvseg_ctx* ctx, const float* X, int32_t P, int32
         std::vector<unsigned> cnt((size_t)n_nodes * n_layers * TR_CMAX);
         RV_HIP(ctx, hipMemcpyAsync(cnt.data(), dCnt, cnt.size() * 4, hipMemcpyDeviceToHost, s));
         RV_HIP(ctx, hipStreamSynchronize(s));
-        RV_HIP(ctx, hipGetLastError());
+        RV_LAUNCH_OK(ctx);
         for (int v = 0; v < n_nodes; v++) {
             if (tree.left[v] != 0) continue;
             tree.mhist[v].resize((size_t)n_layers);

@@ -23,7 +23,9 @@ def _ptr(a):
 class Context:
     """Owns one rvseg_ctx (one per thread and device, as include/rvseg.h requires)."""
 
-    def __init__(self, **params):
+    def __init__(self, schedule=None, **params):
+        """params: fields of rvseg_params; schedule: dict of rvseg_schedule fields (launch-schedule overrides for
+        tests, profiling and tuning -- the library reads no environment variables)."""
         self.params = capi.default_params(**params)
         h = C.c_void_p()
         st = capi.lib().rvseg_create(C.byref(self.params), C.byref(h))
@@ -31,6 +33,28 @@ class Context:
             raise capi.RvsegError(st, capi.lib().rvseg_last_error(None).decode("utf-8", "replace"))
         self.h = h
         self.L = capi.lib()
+        if schedule:
+            self.set_schedule(**schedule)
+
+    def set_schedule(self, **kw):
+        """rvseg_set_schedule: the defaults with the given rvseg_schedule fields replaced."""
+        sc = capi.RvsegSchedule()
+        self.L.rvseg_schedule_default(C.byref(sc))
+        known = {f[0] for f in capi.RvsegSchedule._fields_}
+        for k, v in kw.items():
+            if k not in known:
+                raise TypeError("unknown rvseg_schedule field %r" % k)
+            setattr(sc, k, int(v))
+        capi.check(self.h, self.L.rvseg_set_schedule(self.h, C.byref(sc)))
+
+    def last_schedule(self):
+        """rvseg_last_schedule as a dict; `splat` as a name ("list-major" / "resident").  `vertices` and
+        `planner_fallback` are -1 until poll_status(wait=True) (or a host entry point) has returned."""
+        info = capi.RvsegScheduleInfo()
+        capi.check(self.h, self.L.rvseg_last_schedule(self.h, C.byref(info)))
+        d = {f[0]: getattr(info, f[0]) for f in capi.RvsegScheduleInfo._fields_}
+        d["splat"] = capi.SPLAT_NAMES.get(d["splat"], str(d["splat"]))
+        return d
 
     def close(self):
         if getattr(self, "h", None):
@@ -82,7 +106,10 @@ class Context:
         assert len(class_counts) == L
         tp = capi.RvsegTrainParams()
         self.L.rvseg_train_params_default(C.byref(tp))
+        known = {f[0] for f in capi.RvsegTrainParams._fields_}
         for k, v in train_params.items():
+            if k not in known:
+                raise TypeError("unknown rvseg_train_params field %r" % k)
             setattr(tp, k, v)
         cc = (C.c_int32 * L)(*class_counts)
         size = C.c_size_t()

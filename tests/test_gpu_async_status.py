@@ -81,6 +81,38 @@ def test_device_entry_reports_overflow_through_poll_status(gpu_ctx_factory, orac
         assert np.array_equal(lab[i].ravel(), wl), i
 
 
+def test_pending_overflow_status_survives_a_cloud_crf_on_the_same_context(gpu_ctx_factory):
+    """a frame build that overflowed and whose status nobody has polled yet must not be lost when
+    a cloud CRF (a synchronous lattice build on the SAME context) runs next -- the two read their counters back into
+    separate pinned slots.  Sequence: overflowed segment_frames_device -> crf_infer_device on a small cloud (clean)
+    -> poll_status still reports ERR_CAPACITY for the frame call."""
+    torch = pytest.importorskip("torch")
+    import rovinasemanticsegmentation_amd as rv
+    dev = torch.device("cuda", 0)
+    blob, rgb, depth, calib = _case(2)
+    N = W * H
+    ctx = gpu_ctx_factory(width=W, height=H, use_dense_crf=1, dcrf_iterations=2, label_mode=1, max_batch=2, lattice_capacity_log2=4)
+    ctx.forest_load(blob)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_marg = torch.zeros((2, 17 * N), dtype=torch.float32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    ctx.segment_frames_device(2, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), 0, s)
+    # a clean cloud CRF on the same context (its own lattice, its own overflow retry with the worst-case capacity)
+    rng = np.random.default_rng(5)
+    Np, Cc = 3000, 9
+    U = torch.from_numpy((rng.random((Np, Cc)) * 3).astype(np.float32)).to(dev)
+    F = torch.from_numpy((rng.random((Np, 6)) * 4).astype(np.float32)).to(dev)
+    Q = torch.zeros((Np, Cc), dtype=torch.float32, device=dev)
+    ctx.crf_infer_device(Np, Cc, 6, U.data_ptr(), True, F.data_ptr(), 3.0, 2, Q.data_ptr(), 0, stream=s)
+    torch.cuda.synchronize(dev)
+    assert abs(float(Q.sum(1).mean()) - 1.0) < 1e-4
+    with pytest.raises(rv.capi.RvsegError) as e:
+        ctx.poll_status(wait=True)
+    assert e.value.status == rv.capi.ERR_CAPACITY
+    assert ctx.poll_status(wait=True) == rv.capi.OK     # consumed; the capacity has been raised
+
+
 def test_back_to_back_device_calls_keep_their_own_calibration(gpu_ctx_factory, oracle):
     """The device entry returns without synchronising; its pinned calibration staging must not be
     overwritten by the next call before the copy has run.  Two calls with different

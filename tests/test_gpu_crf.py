@@ -135,27 +135,6 @@ def test_frames_with_crf_bit_exact(gpu_ctx_factory, oracle):
     assert np.allclose(m.sum(1), 1, atol=1e-5)
 
 
-def test_banded_splat_is_bit_exact_too(gpu_ctx_factory, oracle):
-    """RVSEG_SPLAT_BANDS=n cuts every vertex list at n - 1 pixel boundaries and sums band after band
-    (one launch each), carrying the running sums in memory; the additions per vertex stay in point
-    order, so nothing may change.  (Timing experiment of DESIGN.md, section 4.)"""
-    blob = synthetic.make_forest_bytes(seed=22, n_trees=3, leaves_per_tree=256, max_depth=12)
-    forest = oracle.Forest(blob)
-    rgb, depth = synthetic.make_batch(1, holes=True, start=5)
-    calib = synthetic.make_calib()
-    os.environ["RVSEG_SPLAT_BANDS"] = "5"
-    try:
-        ctx = gpu_ctx_factory(use_dense_crf=1, dcrf_iterations=2, label_mode=3)
-        ctx.forest_load(blob)
-        out = ctx.segment_frames(rgb, depth, calib)
-    finally:
-        del os.environ["RVSEG_SPLAT_BANDS"]
-    p = oracle.default_params(dcrf_iterations=2)
-    post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[0], depth[0], calib, label_mode=3)
-    assert np.array_equal(out["marginals"][0], marg)
-    assert np.array_equal(out["labels"][0].ravel(), lab)
-
-
 def test_config5_shape_dual_layer_10_iterations(gpu_ctx_factory, oracle):
     """BASELINE configs[4] at one frame: 1280x960, dual-layer forest, 10 CRF iterations."""
     W, H = 1280, 960
@@ -190,6 +169,26 @@ def test_crf_infer_class_counts_without_a_fused_update(gpu_ctx_factory, oracle, 
     assert np.array_equal(mp, oracle.labels(want, C, 3))
 
 
+def test_two_layers_without_fused_update_share_the_normaliser_table(gpu_ctx_factory, oracle):
+    """label layers with class counts that have no fused update (11 and 13) run side by side on two streams
+    and both read the lattice's per-entry normaliser table; it is filled on the parent stream before the fork."""
+    W, H = 160, 120
+    blob = synthetic.make_forest_bytes(seed=33, n_trees=3, leaves_per_tree=128, max_depth=10, single_classes=11, layer_classes=(11, 13))
+    forest = oracle.Forest(blob)
+    rgb, depth = synthetic.make_batch(3, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, use_dense_crf=1, dcrf_iterations=2, label_mode=1, max_batch=4, unknown_label=[10, 12])
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    for _ in range(2):   # the second call rebuilds the lattice: the table must be refilled, not reused
+        out = ctx.segment_frames(rgb, depth, calib)
+        p = oracle.default_params(width=W, height=H, dcrf_iterations=2)
+        for i in range(3):
+            post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[10, 12])
+            assert np.array_equal(out["marginals"][i], marg), i
+            assert np.array_equal(out["labels"][i].ravel(), lab), i
+
+
 def test_ten_small_frames_uneven_xcd_groups(gpu_ctx_factory, oracle):
     """10 frames in one chunk: 8 launch groups with 2, 2, 1, ... frames each, 6 trees (not a multiple of
     the 4 tree lanes per point), dual layer, fused labels."""
@@ -210,33 +209,6 @@ def test_ten_small_frames_uneven_xcd_groups(gpu_ctx_factory, oracle):
         assert np.array_equal(out["labels"][i].ravel(), lab), i
 
 
-@pytest.mark.parametrize("band", [1, 4, 64])
-def test_queue_splat_is_bit_exact_too(gpu_ctx_factory, oracle, band):
-    """RVSEG_SPLAT_QUEUE=1: the band-major work-queue schedule of the ordered splat -- every vertex
-    list cut into pixel bands, the pieces regrouped per band and run by a persistent grid, chains handed from piece to
-    piece through 8-byte {sum, position} granules.  Each chain is still summed in ascending point order, so nothing
-    may change.  Bands of 1 / 4 / 64 wave-blocks: many tiny pieces, a few per list, (nearly) whole lists."""
-    blob = synthetic.make_forest_bytes(seed=24, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
-    forest = oracle.Forest(blob)
-    W, H = 320, 240
-    rgb, depth = synthetic.make_batch(9, W, H, holes=True, start=2)     # 9 frames: uneven XCD queues
-    calib = synthetic.make_calib(W, H)
-    os.environ["RVSEG_SPLAT_QUEUE"] = "1"
-    os.environ["RVSEG_SPLAT_QUEUE_BAND"] = str(band)
-    try:
-        ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=3, label_mode=1, unknown_label=[8], max_batch=16)
-        ctx.forest_load(blob)
-        out = ctx.segment_frames(rgb, depth, calib)
-    finally:
-        del os.environ["RVSEG_SPLAT_QUEUE"]
-        del os.environ["RVSEG_SPLAT_QUEUE_BAND"]
-    p = oracle.default_params(width=W, height=H, dcrf_iterations=3)
-    for i in range(9):
-        post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
-        assert np.array_equal(out["marginals"][i], marg), i
-        assert np.array_equal(out["labels"][i].ravel(), lab), i
-
-
 @pytest.mark.parametrize("B,band,chunk,window", [(2, 1, 64, 1), (8, 8, 128, 1), (16, 4, 64, 0), (5, 32, 128, -1), (3, 2, 128, 2), (4, 16, 64, -1)])
 def test_resident_band_splat_is_bit_exact(gpu_ctx_factory, oracle, B, band, chunk, window):
     """The resident band schedule of the mean-field splat (default for chunks of more than 16
@@ -250,16 +222,13 @@ def test_resident_band_splat_is_bit_exact(gpu_ctx_factory, oracle, B, band, chun
     W, H = 320, 240
     rgb, depth = synthetic.make_batch(9, W, H, holes=True, start=2)
     calib = synthetic.make_calib(W, H)
-    env = {"RVSEG_SPLAT_RESIDENT": "2", "RVSEG_SPLAT_RESIDENT_B": str(B), "RVSEG_SPLAT_RESIDENT_BAND": str(band),
-           "RVSEG_SPLAT_RESIDENT_CHUNK": str(chunk), "RVSEG_SPLAT_RESIDENT_WINDOW": str(window)}
-    os.environ.update(env)
-    try:
-        ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=3, label_mode=1, unknown_label=[8], max_batch=16)
-        ctx.forest_load(blob)
-        out = ctx.segment_frames(rgb, depth, calib)
-    finally:
-        for k in env:
-            del os.environ[k]
+    sched = dict(splat=2, resident_blocks=B, resident_band=band, resident_chunk=chunk, resident_window=window)
+    ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=3, label_mode=1, unknown_label=[8], max_batch=16,
+                          schedule=sched)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    info = ctx.last_schedule()
+    assert info["splat"] == "resident" and info["planner_fallback"] == 0 and info["resident_blocks"] == B, info
     p = oracle.default_params(width=W, height=H, dcrf_iterations=3)
     for i in range(9):
         post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
@@ -275,15 +244,12 @@ def test_resident_band_splat_falls_back_when_the_planner_gives_up(gpu_ctx_factor
     W, H = 320, 240
     rgb, depth = synthetic.make_batch(2, W, H, holes=True, start=5)
     calib = synthetic.make_calib(W, H)
-    env = {"RVSEG_SPLAT_RESIDENT": "2", "RVSEG_SPLAT_RESIDENT_BAND": "1", "RVSEG_SPLAT_RESIDENT_CAP_TILES": "64"}
-    os.environ.update(env)
-    try:
-        ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=2, label_mode=1, unknown_label=[8], max_batch=16)
-        ctx.forest_load(blob)
-        out = ctx.segment_frames(rgb, depth, calib)
-    finally:
-        for k in env:
-            del os.environ[k]
+    ctx = gpu_ctx_factory(width=W, height=H, multi_layer=0, use_dense_crf=1, dcrf_iterations=2, label_mode=1, unknown_label=[8], max_batch=16,
+                          schedule=dict(splat=2, resident_band=1, resident_cap_tiles=64))
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    info = ctx.last_schedule()   # the fall-back is reported, not silent
+    assert info["splat"] == "resident" and info["planner_fallback"] >= 1, info
     p = oracle.default_params(width=W, height=H, dcrf_iterations=2)
     for i in range(2):
         post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
@@ -305,15 +271,11 @@ def test_resident_band_splat_two_layers_and_fine_lattices(gpu_ctx_factory, oracl
     kw["dcrf_xyz_kernel"] = p.dcrf_xyz_kernel * scale
     kw["dcrf_rgb_kernel"] = p.dcrf_rgb_kernel * scale
     p = oracle.default_params(**kw)
-    env = {"RVSEG_SPLAT_RESIDENT": "2", "RVSEG_SPLAT_RESIDENT_B": str(B)}
-    os.environ.update(env)
-    try:
-        ctx = gpu_ctx_factory(multi_layer=1, use_dense_crf=1, label_mode=1, unknown_label=[7, 8], max_batch=8, lattice_capacity_log2=13, **kw)
-        ctx.forest_load(blob)
-        out = ctx.segment_frames(rgb, depth, calib)
-    finally:
-        for k in env:
-            del os.environ[k]
+    ctx = gpu_ctx_factory(multi_layer=1, use_dense_crf=1, label_mode=1, unknown_label=[7, 8], max_batch=8, lattice_capacity_log2=13,
+                          schedule=dict(splat=2, resident_blocks=B), **kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    assert ctx.last_schedule()["splat"] == "resident"
     for i in range(8):
         post, marg, lab = oracle.segment_frame(p, forest, 1, rgb[i], depth[i], calib, label_mode=1, unknown=[7, 8])
         assert np.array_equal(out["marginals"][i], marg), i
@@ -331,7 +293,7 @@ def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_facto
     rgb, depth = synthetic.make_batch(n_frames, W, H, holes=True, start=3)
     calib = synthetic.make_calib(W, H)
     kw = dict(width=W, height=H, dcrf_iterations=2)
-    ctx = gpu_ctx_factory(multi_layer=0, use_dense_crf=1, label_mode=1, unknown_label=[8], max_batch=64, **kw)
+    ctx = gpu_ctx_factory(multi_layer=0, use_dense_crf=1, label_mode=1, unknown_label=[8], max_batch=64, schedule=dict(splat=2), **kw)
     ctx.forest_load(blob)
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
@@ -340,13 +302,11 @@ def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_facto
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     d_marg = torch.zeros((n_frames, 9 * N), dtype=torch.float32, device=dev)
     d_lab = torch.full((n_frames, N), -99, dtype=torch.int8, device=dev)
-    os.environ["RVSEG_SPLAT_RESIDENT"] = "2"
-    try:
-        ctx.segment_frames_device(n_frames, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
-                                  torch.cuda.current_stream(dev).cuda_stream)
-    finally:
-        del os.environ["RVSEG_SPLAT_RESIDENT"]
+    ctx.segment_frames_device(n_frames, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream)
     assert ctx.poll_status(wait=True) == 0
+    info = ctx.last_schedule()
+    assert info["splat"] == "resident" and info["planner_fallback"] == 0 and info["n_frames"] == n_frames, info
     torch.cuda.synchronize(dev)
     marg = d_marg.cpu().numpy(); lab = d_lab.cpu().numpy()
     p = oracle.default_params(**kw)
@@ -359,7 +319,7 @@ def test_resident_band_splat_default_path_with_uneven_frame_counts(gpu_ctx_facto
 def test_config5_chunk_resident_schedule_equals_list_major_walk(gpu_ctx_factory, oracle):
     """BASELINE configs[4] as bench.py runs it on one GPU: a chunk of 16 frames of 1280x960 with two label layers and 10
     CRF iterations (19.7 M points: the library takes the resident band schedule by itself, one launch per layer on two
-    streams).  The same chunk with RVSEG_SPLAT_RESIDENT=0 walks the lists the list-major way; both orders of work sum
+    streams).  The same chunk with schedule.splat = 1 walks the lists the list-major way; both orders of work sum
     every chain in ascending point order, so marginals and labels have to be identical to the bit -- and frame 5 is
     checked against the CPU oracle as well."""
     torch = pytest.importorskip("torch")
@@ -373,18 +333,15 @@ def test_config5_chunk_resident_schedule_equals_list_major_walk(gpu_ctx_factory,
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     kw = dict(width=W, height=H, multi_layer=1, use_dense_crf=1, dcrf_iterations=10, label_mode=1, unknown_label=[7, 8], max_batch=n)
     results = []
-    for resident in ("1", "0"):
-        ctx = gpu_ctx_factory(**kw)
+    for splat, name in ((0, "resident"), (1, "list-major")):   # 0: the library's own choice for this shape
+        ctx = gpu_ctx_factory(schedule=dict(splat=splat), **kw)
         ctx.forest_load(blob)
         d_marg = torch.zeros((n, 17 * N), dtype=torch.float32, device=dev)
         d_lab = torch.full((n, 2 * N), -99, dtype=torch.int8, device=dev)
-        os.environ["RVSEG_SPLAT_RESIDENT"] = resident
-        try:
-            ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
-                                      torch.cuda.current_stream(dev).cuda_stream)
-            assert ctx.poll_status(wait=True) == 0
-        finally:
-            del os.environ["RVSEG_SPLAT_RESIDENT"]
+        ctx.segment_frames_device(n, d_rgb.data_ptr(), d_depth.data_ptr(), calib, 0, d_marg.data_ptr(), d_lab.data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream)
+        assert ctx.poll_status(wait=True) == 0
+        assert ctx.last_schedule()["splat"] == name
         torch.cuda.synchronize(dev)
         results.append((d_marg, d_lab))
         ctx.close()
