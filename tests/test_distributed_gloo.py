@@ -53,7 +53,8 @@ def _worker(rank, world, port, n_frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 8), (2, 5), (3, 7)])
+# (8, 256): BASELINE configs[3] -- the local map of 256 key frames over 8 ranks, 32 frames each
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (2, 5), (3, 7), (8, 256)])
 def test_label_gather_gloo(world, n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -126,7 +127,7 @@ def _gatherer_worker(rank, world, port, n_frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 6), (3, 8)])
+@pytest.mark.parametrize("world,n_frames", [(2, 6), (3, 8), (8, 256)])
 def test_frame_gatherer_reuses_its_buffers(world, n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
