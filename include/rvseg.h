@@ -148,12 +148,31 @@ void rvseg_train_params_default(rvseg_train_params *tp);
 /* X: P x D host floats (one DataPoint per row), labels: P x n_layers class indices (DataStorage's multi labels),
  * class_counts per layer (at most 16 each).  Writes a forest.dat image (multi_histograms = the "shared" forest of
  * train.cpp:231; with one layer also `histograms`), loadable with rvseg_forest_load_mem and by the reference.
- * forest_out may be NULL to query *size_out.  Search = the reference's criterion (minimum of E(left) + E(right),
- * thresholds at midpoints of adjacent distinct values: exact for byte-valued features, 256 uniform bins for
- * the others); leaf histograms exactly as updateMultiHistograms computes them (learning.cpp:960-1012). */
+ * Search = the reference's: minimum of E(left) + E(right) (EfficientEntropyHistogram, fastlog2) over the thresholds at
+ * midpoints of adjacent values at least 1e-6 apart (learning.cpp:578-592) -- exact for every feature: byte-valued
+ * features through per-value histograms, the others through a sort per level; leaf histograms exactly as
+ * updateMultiHistograms computes them (learning.cpp:960-1012); nodes numbered as the reference's depth-first stack
+ * would.  Equal seeds give equal bytes, and the bytes equal the CPU oracle's depth-first learner (tests).
+ * The trained model is also kept on the context: when out_cap is too small (RVSEG_ERR_INVALID_ARG, *size_out = needed
+ * size) or forest_out is NULL, fetch it with rvseg_forest_train_result instead of training again. */
 rvseg_status rvseg_forest_train(rvseg_ctx *ctx, const float *X, int32_t P, int32_t D, const int32_t *labels,
                                 int32_t n_layers, const int32_t *class_counts, const rvseg_train_params *tp,
                                 void *forest_out, size_t out_cap, size_t *size_out);
+rvseg_status rvseg_forest_train_result(rvseg_ctx *ctx, void *forest_out, size_t out_cap, size_t *size_out);
+/* Training straight from labelled key frames: replaces the extraction loop of src/train.cpp:115-147 as well.  Features
+ * are extracted on the device (FeatureExtractor::extract, WITH_POSITIVE_LABEL branch: stride-grid points with valid
+ * depth whose labels are all >= 0, include/feature_extractor.h:93-121) and packed there (Lab patch bytes as bytes,
+ * depth / height / normal as floats); no P x D float matrix exists anywhere.
+ *   rgb n x H x W x 3, depth_mm n x H x W, calib n x 21 (all host memory, the context's width / height / stride);
+ *   labels n x L x H x W int8 (label_type = char, include/defines.h), < 0 = unlabelled
+ *   augment != 0: the reference's augmentation -- every frame with colour offsets -20, 0, +20 (`color += a` on the
+ *   8UC3 image, i.e. OpenCV's Scalar(a,0,0,0): channel 0 only, saturated) and each of those also flipped horizontally
+ *   (colour, depth and labels, same calibration): six extractions per frame, in the reference's order
+ *   n_examples_out (optional): training points extracted. */
+rvseg_status rvseg_forest_train_frames(rvseg_ctx *ctx, int32_t n_frames, const uint8_t *rgb, const uint16_t *depth_mm,
+                                       const float *calib, const int8_t *labels, int32_t n_layers,
+                                       const int32_t *class_counts, int32_t augment, const rvseg_train_params *tp,
+                                       void *forest_out, size_t out_cap, size_t *size_out, int32_t *n_examples_out);
 /* n_layers / class_counts describe the active mode (multi_layer or single). */
 rvseg_status rvseg_forest_info(const rvseg_ctx *ctx, int32_t *n_trees, int32_t *n_nodes_total,
                                int32_t *max_depth, int32_t *n_layers,

@@ -38,10 +38,9 @@ class _Lattice(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "rvseg_oracle.c")
-    hdr = os.path.join(_HERE, "rvseg_oracle.h")
+    srcs = [os.path.join(_HERE, n) for n in ("rvseg_oracle.c", "rvseg_oracle_train.c", "rvseg_oracle.h")]
     stale = (not os.path.exists(so)) or any(
-        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in (src, hdr))
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", _HERE, "lib"])
     return so
@@ -84,6 +83,8 @@ def lib():
         L.orc_crf_inference_multi.argtypes = [ip, ip, ip, vp, vp, vp, vp, ip, vp]
         L.orc_frame_crf_features.argtypes = [C.POINTER(OrcParams), vp, vp, vp]
         L.orc_segment_frame.argtypes = [C.POINTER(OrcParams), vp, ip, vp, vp, vp, vp, vp, vp, ip, vp]
+        L.orc_forest_train.argtypes = [vp, ip, ip, vp, ip, vp, ip, ip, ip, ip, ip, ip, fp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.orc_free.argtypes = [vp]
         L.orc_lab_gamma_tab.restype = C.POINTER(C.c_ushort)
         L.orc_lab_cbrt_tab.restype = C.POINTER(C.c_ushort)
         L.orc_lab_coeffs.restype = C.POINTER(C.c_int)
@@ -138,6 +139,25 @@ class Forest:
         if getattr(self, "h", None):
             lib().orc_forest_free(self.h)
             self.h = None
+
+
+def forest_train(X, labels, class_counts, num_trees=4, max_depth=30, min_split_examples=50, min_child_split_examples=1,
+                 num_features=0, use_bootstrap=1, smoothing=1.0, seed=1):
+    """orc_forest_train: the CPU learner (depth-first, sorts).  Returns the forest.dat bytes."""
+    X = np.ascontiguousarray(X, np.float32)
+    labels = np.ascontiguousarray(np.asarray(labels, np.int32).reshape(X.shape[0], -1))
+    cc = np.asarray(class_counts, np.int32)
+    out = C.c_void_p()
+    size = C.c_size_t()
+    rc = lib().orc_forest_train(_p(X), X.shape[0], X.shape[1], _p(labels), labels.shape[1], _p(cc), num_trees, max_depth,
+                                min_split_examples, min_child_split_examples, num_features, use_bootstrap, smoothing, seed,
+                                C.byref(out), C.byref(size))
+    if rc != 0:
+        raise ValueError("orc_forest_train: bad arguments")
+    try:
+        return C.string_at(out, size.value)
+    finally:
+        lib().orc_free(out)
 
 
 def bgr2lab(img):

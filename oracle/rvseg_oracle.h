@@ -180,6 +180,16 @@ int orc_segment_frame(const orc_params *p, const orc_forest *f, int multi, const
                       const uint16_t *depth, const float *calib, float *posteriors, float *marginals,
                       int8_t *labels, int label_mode, const int *unknown_labels);
 
+/* ------------------------------------------------------------------ forest learner */
+/* DecisionTreeLearner::learn (multi-layer branch, learning.cpp:410-662) + updateMultiHistograms (:960-1012) +
+ * RandomForest::write, depth-first with sorts; see rvseg_oracle_train.c for the build-owned definitions (random
+ * choices keyed by (seed, tree, node path), objective from the class counts).  X: P x D row-major, labels: P x L.
+ * *forest_out receives a malloc'ed forest.dat image (orc_free).  Returns 0 on success. */
+int orc_forest_train(const float *X, int P, int D, const int32_t *labels, int n_layers, const int32_t *class_counts,
+                     int num_trees, int max_depth, int min_split_examples, int min_child_split_examples, int num_features,
+                     int use_bootstrap, float smoothing, uint64_t seed, void **forest_out, size_t *size_out);
+void orc_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

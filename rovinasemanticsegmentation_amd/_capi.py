@@ -30,6 +30,7 @@ SYMBOLS = [
     "rvseg_train_params_default", "rvseg_forest_train",
     "rvseg_comm_unique_id", "rvseg_comm_init", "rvseg_comm_destroy", "rvseg_gather_frames",
     "rvseg_schedule_default", "rvseg_set_schedule", "rvseg_last_schedule",
+    "rvseg_forest_train_result", "rvseg_forest_train_frames",
 ]
 
 
@@ -134,6 +135,9 @@ def lib():
     L.rvseg_train_params_default.argtypes = [C.POINTER(RvsegTrainParams)]
     L.rvseg_train_params_default.restype = None
     L.rvseg_forest_train.argtypes = [vp, vp, i32, i32, vp, i32, vp, C.POINTER(RvsegTrainParams), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rvseg_forest_train_result.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.rvseg_forest_train_frames.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.POINTER(RvsegTrainParams), vp, C.c_size_t,
+                                            C.POINTER(C.c_size_t), C.POINTER(i32)]
     L.rvseg_comm_unique_id.argtypes = [vp]
     L.rvseg_comm_init.argtypes = [vp, i32, i32, vp]
     L.rvseg_comm_destroy.argtypes = [vp]

@@ -72,6 +72,7 @@ struct rvseg_ctx {
     rvseg::StageTimer timer;
     struct Impl;
     Impl* impl = nullptr;  // frame / crf pipeline state (rvseg_pipeline.hip)
+    std::vector<uint8_t> trained_model;   // forest.dat image of the last rvseg_forest_train* call (rvseg_forest_train_result)
     void* comm = nullptr;  // RCCL communicator of the local-map gather (rvseg_comm.cpp), or null
     int comm_rank = 0, comm_world = 0;
 };

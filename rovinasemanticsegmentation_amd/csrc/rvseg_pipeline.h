@@ -50,6 +50,8 @@ struct Pipeline {
 };
 
 rvseg_status pipeline_init(rvseg_ctx* ctx);
+// stages the per-frame A = R*Kinv, t of n calibrations (21 floats each) and enqueues their copy to im->calibA
+rvseg_status upload_calib(rvseg_ctx* ctx, Pipeline* im, const float* calib, int n, hipStream_t s);
 void timer_reset(rvseg_ctx* ctx);
 void timer_mark(rvseg_ctx* ctx, const char* name, hipStream_t s);
 

@@ -149,7 +149,7 @@ static void calib_to_A(const float* calib, float* out12) {
     out12[9] = t[0]; out12[10] = t[1]; out12[11] = t[2];
 }
 
-static rvseg_status upload_calib(rvseg_ctx* ctx, Pipeline* im, const float* calib, int n, hipStream_t s) {
+rvseg_status upload_calib(rvseg_ctx* ctx, Pipeline* im, const float* calib, int n, hipStream_t s) {
     const int slot = im->calib_next;
     im->calib_next = (slot + 1) % Pipeline::CALIB_RING;
     if (!im->calib_ev[slot]) RV_HIP(ctx, hipEventCreateWithFlags(&im->calib_ev[slot], hipEventDisableTiming));

@@ -104,6 +104,14 @@ class Context:
         P, D = X.shape
         L = labels.shape[1]
         assert len(class_counts) == L
+        tp = self._train_params(train_params)
+        cc = (C.c_int32 * L)(*class_counts)
+        size = C.c_size_t()
+        # trains once (the model stays on the context), then fetches it into a buffer of the right size
+        capi.check(self.h, self.L.rvseg_forest_train(self.h, _ptr(X), P, D, _ptr(labels), L, cc, C.byref(tp), None, 0, C.byref(size)))
+        return self._trained_model(size.value)
+
+    def _train_params(self, train_params):
         tp = capi.RvsegTrainParams()
         self.L.rvseg_train_params_default(C.byref(tp))
         known = {f[0] for f in capi.RvsegTrainParams._fields_}
@@ -111,17 +119,33 @@ class Context:
             if k not in known:
                 raise TypeError("unknown rvseg_train_params field %r" % k)
             setattr(tp, k, v)
+        return tp
+
+    def _trained_model(self, size):
+        buf = C.create_string_buffer(size)
+        got = C.c_size_t()
+        capi.check(self.h, self.L.rvseg_forest_train_result(self.h, buf, size, C.byref(got)))
+        return buf.raw[:got.value]
+
+    def forest_train_frames(self, rgb, depth, calib, labels, class_counts, augment=False, **train_params):
+        """rvseg_forest_train_frames: rgb (n, H, W, 3) uint8, depth (n, H, W) uint16, labels (n, L, H, W) int8 (< 0 =
+        unlabelled).  Returns (forest.dat bytes, number of training points)."""
+        p = self.params
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        labels = np.ascontiguousarray(labels, np.int8)
+        n = rgb.shape[0]
+        L = labels.shape[1]
+        assert rgb.shape == (n, p.height, p.width, 3) and depth.shape == (n, p.height, p.width)
+        assert labels.shape == (n, L, p.height, p.width) and len(class_counts) == L
+        calib = np.ascontiguousarray(np.broadcast_to(np.asarray(calib, np.float32).reshape(-1, 21), (n, 21)))
+        tp = self._train_params(train_params)
         cc = (C.c_int32 * L)(*class_counts)
         size = C.c_size_t()
-        cap = 64 << 20
-        while True:
-            buf = C.create_string_buffer(cap)
-            st = self.L.rvseg_forest_train(self.h, _ptr(X), P, D, _ptr(labels), L, cc, C.byref(tp), buf, cap, C.byref(size))
-            if st == capi.ERR_INVALID_ARG and size.value > cap:
-                cap = size.value
-                continue
-            capi.check(self.h, st)
-            return buf.raw[:size.value]
+        n_ex = C.c_int32()
+        capi.check(self.h, self.L.rvseg_forest_train_frames(self.h, n, _ptr(rgb), _ptr(depth), _ptr(calib), _ptr(labels), L, cc,
+                                                            1 if augment else 0, C.byref(tp), None, 0, C.byref(size), C.byref(n_ex)))
+        return self._trained_model(size.value), n_ex.value
 
     def poll_status(self, wait=True):
         """Status of the asynchronous part of the last segment_frames_device call: capi.OK,
