@@ -9,8 +9,19 @@
 //   Segmenter::Segmenter(..., config_file, ...)   :38-129     Segmenter(const Config&)
 //       throws std::runtime_error                 :65,198          throws std::runtime_error
 //       loads forest.dat, silently continues if missing :106-115   throws (RVSEG_ERR_IO)
-//   processFramesFromQueueInternalRF()            :323-443    processFrames(): one call per
-//       posteriors vector [layer][y][x][class]    :413-431        dequeued batch, same layout
+//   onNewNode(): (seq, depth, colour) per camera  :245-293    enqueueFrame(camera, seq, colour, depth)
+//       pushed onto _image_queues[camera]         :283
+//   processFramesFromQueueInternalRF()            :323-443    processFramesFromQueueInternalRF(): the worker's loop
+//       pops ONE frame per iteration              :340-346        body; pops up to max_batch frames over all cameras into
+//       pushes (seq, posteriors) per camera       :434            ONE rvseg_segment_frames call, pushes per camera in order
+//       posteriors vector [layer][y][x][class]    :413-431    processFrames(): the body for an explicit batch, same layout
+//   onNewLocalMap(): push onto _local_map_queue   :300-304    onNewLocalMap(LocalMap)
+//   processMapFromQueue(): wait for the newest    :518-719    processMapFromQueue(): false while the map has to be postponed
+//       result of every camera, drop skipped      :527-553        (:527-553), else drops skipped results, matches by seq
+//       results, match by seq, fuse, label, store :589-616        (:589-597), fuses, labels, stores under the map id
+//   the two detached worker threads               :227-232    start() / stop(): the same two loops, joined on stop
+//   (no counterpart: single process)                          commInit() / gatherLabels(): the local-map label gather over
+//                                                                 RCCL when key frames are sharded over several GPUs
 //   processMapFromQueue() CRF branch              :628-658    processCloud(): DenseCRF per layer
 //       label = max marginal > 2.0/C else Unknown :646-657        same rule (RVSEG_LABEL_CRF)
 //   processMapFromQueue() no-CRF branch           :660-681    labelCloud(): RVSEG_LABEL_NOCRF rule
@@ -27,10 +38,16 @@
 #ifndef RVSEG_SEGMENTER_HPP
 #define RVSEG_SEGMENTER_HPP
 
+#include <array>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <deque>
 #include <fstream>
 #include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -90,6 +107,20 @@ struct LocalMapSegmentationRequest {
 struct LocalMapSegmentationResponse {
     int32_t local_map_id = 0;
     std::vector<uint8_t> point_labels;   // requested layers concatenated, each cloud_size long (segmenter.cpp:757-768)
+};
+
+// One fps_mapper::MultiImageMapNode of a local map as the fusion loop needs it (segmenter.cpp:571-621).  The projector is
+// external to the reference (fps_mapper::MultiProjector::project, :578), so the caller hands over its result.
+struct LocalMapNode {
+    std::vector<int> subimage_seqs;        // m_multi->subimageSeqs(): the depth sequence number of every camera's sub-image
+    std::vector<int32_t> index_image;      // IndexImage, cameras stacked row-wise: (n_cameras * H) x W, < 0 = no cloud point (:601-604)
+};
+// One fps_mapper::LocalMap: its id, nodes and cloud (xyz in the map frame, rgb in [0, 1]; :560, :629-637)
+struct LocalMap {
+    int32_t id = 0;
+    std::vector<LocalMapNode> nodes;
+    size_t cloud_size = 0;
+    std::vector<float> cloud_xyz, cloud_rgb;   // cloud_size x 3 each (only read with use_dense_crf)
 };
 
 // One point of the cloud as the debug dumps write it.  fps_mapper's Cloud::write is not in the reference tree
@@ -210,8 +241,163 @@ public:
         }
     }
     ~Segmenter() {
+        stop();
         if (map_ctx_) rvseg_destroy(map_ctx_);
         if (ctx_) rvseg_destroy(ctx_);
+    }
+
+    // ---- the queue layer (segmenter.h:94-108): _image_queues / _result_queues under _frame_mtx, _local_map_queue under
+    //      _cloud_processing_mtx ---------------------------------------------------------------------------------------
+    // initializeProjector's camera table (segmenter.cpp:161-205): one calibration (K^-1, R, t: 21 floats) per camera, in the
+    // mapper's camera order; sizes the queues (:207-225).
+    void setCameras(int n_cameras, const float* calib) {
+        std::lock_guard<std::mutex> g(frame_mtx_);
+        camera_calib_.assign(calib, calib + (size_t)n_cameras * 21);
+        image_queues_.assign((size_t)n_cameras, {});
+        result_queues_.assign((size_t)n_cameras, {});
+    }
+    int cameraCount() const { return (int)image_queues_.size(); }
+
+    // onNewNode for one camera's sub-image (segmenter.cpp:271-284): the frames are copied (the reference holds cv::Mat
+    // references) and pushed with their depth sequence number.
+    void enqueueFrame(int camera, int seq, const uint8_t* color, const uint16_t* depth) {
+        const size_t npix = (size_t)conf_.width * conf_.height;
+        QueuedFrame f;
+        f.seq = seq;
+        f.color.assign(color, color + npix * 3);
+        f.depth.assign(depth, depth + npix);
+        std::lock_guard<std::mutex> g(frame_mtx_);
+        if (camera < 0 || (size_t)camera >= image_queues_.size()) throw std::runtime_error("Found a frame for an unknown camera!");   // :203
+        image_queues_[(size_t)camera].push_back(std::move(f));
+    }
+
+    // One iteration of the RF worker (segmenter.cpp:334-443).  The reference pops ONE frame per iteration and holds
+    // _frame_mtx while it extracts and classifies; here up to max_batch queued frames -- cameras visited round robin like
+    // the reference's `for i < max` loop, every camera in FIFO order -- go through ONE rvseg_segment_frames call (a
+    // chunk of 64 frames runs at 12x the per-frame rate of single-frame calls on MI355X), the mutex is held only to pop
+    // and to push.  Returns the number of frames processed (0: nothing queued; the reference sleeps 1 ms then, :438-439).
+    int processFramesFromQueueInternalRF() {
+        std::vector<QueuedFrame> batch;
+        std::vector<int> cams;
+        {
+            std::lock_guard<std::mutex> g(frame_mtx_);
+            bool any = true;
+            while (any && (int)batch.size() < conf_.max_batch) {
+                any = false;
+                for (size_t i = 0; i < image_queues_.size() && (int)batch.size() < conf_.max_batch; i++) {
+                    if (image_queues_[i].empty()) continue;
+                    batch.push_back(std::move(image_queues_[i].front()));   // :340-341
+                    image_queues_[i].pop_front();
+                    cams.push_back((int)i);
+                    any = true;
+                }
+            }
+        }
+        if (batch.empty()) return 0;
+        const size_t npix = (size_t)conf_.width * conf_.height;
+        const int n = (int)batch.size();
+        std::vector<uint8_t> color((size_t)n * npix * 3);
+        std::vector<uint16_t> depth((size_t)n * npix);
+        std::vector<float> calib((size_t)n * 21);
+        for (int k = 0; k < n; k++) {
+            std::memcpy(color.data() + (size_t)k * npix * 3, batch[(size_t)k].color.data(), npix * 3);
+            std::memcpy(depth.data() + (size_t)k * npix, batch[(size_t)k].depth.data(), npix * 2);
+            std::memcpy(calib.data() + (size_t)k * 21, camera_calib_.data() + (size_t)cams[(size_t)k] * 21, 21 * sizeof(float));   // :349
+        }
+        std::vector<std::vector<float>> post = processFrames(n, color.data(), depth.data(), calib.data());
+        std::lock_guard<std::mutex> g(frame_mtx_);
+        for (int k = 0; k < n; k++)   // per camera the pop order is the push order: sequence numbers stay ascending (:434)
+            result_queues_[(size_t)cams[(size_t)k]].emplace_back(batch[(size_t)k].seq, std::move(post[(size_t)k]));
+        return n;
+    }
+
+    // read access for tests / monitoring: (seq, posteriors) pairs waiting for the fusion thread
+    size_t resultCount(int camera) const { std::lock_guard<std::mutex> g(frame_mtx_); return result_queues_.at((size_t)camera).size(); }
+    std::pair<int, std::vector<float>> resultAt(int camera, size_t k) const { std::lock_guard<std::mutex> g(frame_mtx_); return result_queues_.at((size_t)camera).at(k); }
+
+    void onNewLocalMap(LocalMap lmap) {   // segmenter.cpp:300-304
+        std::lock_guard<std::mutex> g(cloud_processing_mtx_);
+        local_map_queue_.push_back(std::move(lmap));
+    }
+
+    // One iteration of the fusion worker (segmenter.cpp:521-719).  false: no map queued, or the front map has to be
+    // postponed because some camera's newest result is older than the map's last sub-image (:527-553; an empty result
+    // queue counts as "not there yet" -- the reference reads .back() of an empty deque).  true: the front map was
+    // processed: per node and camera results older than the wanted sequence number are dropped (:589-592), an exact
+    // match is fused (:594-616), a missing one is skipped with a message (:618-621); then CRF / no-CRF labelling and
+    // the store under the map id (:628-713).
+    bool processMapFromQueue() {
+        LocalMap lmap;
+        {
+            std::lock_guard<std::mutex> g(cloud_processing_mtx_);
+            if (local_map_queue_.empty()) return false;
+            const LocalMap& front = local_map_queue_.front();
+            std::vector<int> last_ids;
+            for (const LocalMapNode& nd : front.nodes) last_ids = nd.subimage_seqs;   // :531-538: the LAST node's ids
+            {
+                std::lock_guard<std::mutex> f(frame_mtx_);
+                for (size_t i = 0; i < last_ids.size() && i < result_queues_.size(); i++)
+                    if (result_queues_[i].empty() || result_queues_[i].back().first < last_ids[i]) return false;   // :541-546
+            }
+            lmap = std::move(local_map_queue_.front());
+            local_map_queue_.pop_front();   // :556
+        }
+        const size_t npix = (size_t)conf_.width * conf_.height;
+        const size_t per = (size_t)total_labels_ * npix;
+        std::vector<int32_t> index_images;
+        std::vector<float> posteriors;
+        int n_images = 0;
+        for (const LocalMapNode& nd : lmap.nodes) {
+            for (size_t i = 0; i < nd.subimage_seqs.size() && i < result_queues_.size(); i++) {
+                std::lock_guard<std::mutex> f(frame_mtx_);
+                std::deque<std::pair<int, std::vector<float>>>& q = result_queues_[i];
+                while (!q.empty() && q.front().first < nd.subimage_seqs[i]) q.pop_front();   // "Drop skipped maps", :589-592
+                if (!q.empty() && q.front().first == nd.subimage_seqs[i]) {
+                    if (nd.index_image.size() < (i + 1) * npix) throw std::runtime_error("index image smaller than n_cameras * H x W");
+                    index_images.insert(index_images.end(), nd.index_image.begin() + (std::ptrdiff_t)(i * npix),
+                                        nd.index_image.begin() + (std::ptrdiff_t)((i + 1) * npix));   // rows y + i*_camera_h, :601
+                    posteriors.insert(posteriors.end(), q.front().second.begin(), q.front().second.end());
+                    q.pop_front();
+                    n_images++;
+                } else {
+                    std::fprintf(stderr, "Couldn't find a semantic map for key frame: %d\n", nd.subimage_seqs[i]);   // :618-621
+                }
+            }
+        }
+        if (posteriors.size() != (size_t)n_images * per) throw std::runtime_error("result queue entry of the wrong size");
+        processMap(lmap.id, n_images, index_images.data(), posteriors.data(), lmap.cloud_size, lmap.cloud_xyz.data(), lmap.cloud_rgb.data());
+        return true;
+    }
+
+    // The two worker threads of initializeProjector (segmenter.cpp:227-232), joinable instead of detached.  Each loop
+    // sleeps 1 ms when it has nothing to do (:438-439, :549-551).  An exception of a worker ends that worker and is
+    // re-thrown by stop().
+    void start() {
+        if (running_.exchange(true)) return;
+        rf_thread_ = std::thread([this] { worker([this] { return processFramesFromQueueInternalRF() > 0; }, rf_error_); });
+        map_thread_ = std::thread([this] { worker([this] { return processMapFromQueue(); }, map_error_); });
+    }
+    void stop() {
+        if (!running_.exchange(false)) return;
+        if (rf_thread_.joinable()) rf_thread_.join();
+        if (map_thread_.joinable()) map_thread_.join();
+        std::string err = rf_error_.empty() ? map_error_ : rf_error_;
+        rf_error_.clear(); map_error_.clear();
+        if (!err.empty()) throw std::runtime_error(err);
+    }
+
+    // ---- key frames sharded over several GPUs (one Segmenter per GPU, in its own process or thread): the local-map label
+    //      gather to the fusion rank over RCCL / xGMI (rvseg_comm_*, include/rvseg.h) ------------------------------------------
+    static std::array<uint8_t, RVSEG_COMM_ID_BYTES> commUniqueId() {   // rank 0 creates it, the host distributes it
+        std::array<uint8_t, RVSEG_COMM_ID_BYTES> id{};
+        if (rvseg_comm_unique_id(id.data()) != RVSEG_OK) throw std::runtime_error("rvseg_comm_unique_id failed (librccl.so missing?)");
+        return id;
+    }
+    void commInit(int rank, int world, const std::array<uint8_t, RVSEG_COMM_ID_BYTES>& id) { check(rvseg_comm_init(ctx_, rank, world, id.data())); }
+    // every rank's bytes_per_rank bytes of device memory (int8 labels n x L x H x W, or fp32 posteriors for the
+    // order-preserving fusion) land at d_recv + rank * bytes_per_rank on `root`; enqueued on hip_stream
+    void gatherLabels(const void* d_local, size_t bytes_per_rank, void* d_recv, int root, void* hip_stream) {
+        check(rvseg_gather_frames(ctx_, d_local, bytes_per_rank, d_recv, root, hip_stream));
     }
     Segmenter(const Segmenter&) = delete;
     Segmenter& operator=(const Segmenter&) = delete;
@@ -236,8 +422,9 @@ public:
         std::vector<float> energy(cloud_size * (size_t)C), Q(cloud_size * (size_t)C);
         for (size_t i = 0; i < energy.size(); i++) energy[i] = -unaries[i];   // crf.setUnaryEnergy(-unaries[l]), :642
         std::vector<int8_t> map(cloud_size);
-        check(rvseg_crf_infer(ctx_, (int32_t)cloud_size, C, 6, energy.data(), pairwise, conf_.dcrf_kernel_weight,
-                              conf_.dcrf_iterations, Q.data(), map.data(), RVSEG_LABEL_CRF, conf_.layers[layer].unknown_label));
+        rvseg_ctx* mc = map_ctx();   // the fusion thread's context: the RF worker may be inside ctx_ at this moment
+        check(rvseg_crf_infer(mc, (int32_t)cloud_size, C, 6, energy.data(), pairwise, conf_.dcrf_kernel_weight,
+                              conf_.dcrf_iterations, Q.data(), map.data(), RVSEG_LABEL_CRF, conf_.layers[layer].unknown_label), mc);
         return std::vector<unsigned char>(map.begin(), map.end());
     }
 
@@ -245,7 +432,8 @@ public:
     std::vector<unsigned char> labelCloud(size_t layer, size_t cloud_size, const float* unaries) {
         const int C = (int)conf_.layers.at(layer).classes.size();
         std::vector<int8_t> map(cloud_size);
-        check(rvseg_label_values(ctx_, unaries, (int32_t)cloud_size, C, RVSEG_LABEL_NOCRF, conf_.layers[layer].unknown_label, map.data()));
+        rvseg_ctx* mc = map_ctx();
+        check(rvseg_label_values(mc, unaries, (int32_t)cloud_size, C, RVSEG_LABEL_NOCRF, conf_.layers[layer].unknown_label, map.data()), mc);
         return std::vector<unsigned char>(map.begin(), map.end());
     }
 
@@ -257,7 +445,8 @@ public:
         std::vector<int32_t> cc;
         for (const Layer& l : conf_.layers) cc.push_back((int32_t)l.classes.size());
         std::vector<float> flat(cloud_size * (size_t)total_labels_);
-        check(rvseg_fuse_posteriors(ctx_, n_images, index_images, posteriors, (int32_t)cc.size(), cc.data(), (int32_t)cloud_size, flat.data()));
+        rvseg_ctx* mc = map_ctx();
+        check(rvseg_fuse_posteriors(mc, n_images, index_images, posteriors, (int32_t)cc.size(), cc.data(), (int32_t)cloud_size, flat.data()), mc);
         std::vector<std::vector<float>> out(cc.size());
         size_t off = 0;
         for (size_t l = 0; l < cc.size(); l++) {
@@ -292,8 +481,9 @@ public:
     // L x cloud_size labels.  Nothing crosses PCIe.
     void processMapDevice(int n_images, const int32_t* d_index_images, const float* d_posteriors, size_t cloud_size,
                           const float* d_cloud_xyz, const float* d_cloud_rgb, int8_t* d_labels_out, void* hip_stream) {
-        check(rvseg_process_map_device(map_ctx(), n_images, d_index_images, d_posteriors, (int32_t)cloud_size, d_cloud_xyz, d_cloud_rgb,
-                                       d_labels_out, nullptr, hip_stream));
+        rvseg_ctx* mc = map_ctx();
+        check(rvseg_process_map_device(mc, n_images, d_index_images, d_posteriors, (int32_t)cloud_size, d_cloud_xyz, d_cloud_rgb,
+                                       d_labels_out, nullptr, hip_stream), mc);
     }
 
     // "Save data for the service based on the map id" (segmenter.cpp:711-713)
@@ -340,8 +530,11 @@ public:
     unsigned totalLabels() const { return total_labels_; }
     rvseg_ctx* context() { return ctx_; }
     // The fusion thread's context: same model and parameters, CRF switch as configured (the frame context keeps
-    // use_dense_crf = 0 because the node runs the CRF on the fused cloud only).  Created on first use.
+    // use_dense_crf = 0 because the node runs the CRF on the fused cloud only).  Created on first use; everything the
+    // fusion thread calls (fusePosteriors, processCloud, labelCloud, processMap*) runs on it, everything the RF worker
+    // calls (processFrames*) on the frame context -- one context per thread, as include/rvseg.h requires.
     rvseg_ctx* map_ctx() {
+        std::lock_guard<std::mutex> g(map_ctx_mtx_);
         if (map_ctx_) return map_ctx_;
         rvseg_params p;
         rvseg_params_default(&p);
@@ -366,8 +559,23 @@ public:
     }
 
 private:
-    void check(rvseg_status st) const {
-        if (st != RVSEG_OK) throw std::runtime_error(std::string(rvseg_status_string(st)) + ": " + rvseg_last_error(ctx_));
+    struct QueuedFrame {
+        int seq = 0;
+        std::vector<uint8_t> color;
+        std::vector<uint16_t> depth;
+    };
+    template <class Step>
+    void worker(Step step, std::string& error) {
+        try {
+            while (running_.load()) {
+                if (!step()) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+        } catch (const std::exception& e) {
+            error = e.what();
+        }
+    }
+    void check(rvseg_status st, const rvseg_ctx* c = nullptr) const {
+        if (st != RVSEG_OK) throw std::runtime_error(std::string(rvseg_status_string(st)) + ": " + rvseg_last_error(c ? c : ctx_));
     }
     [[noreturn]] void fail(const std::string& msg) {
         rvseg_destroy(ctx_);
@@ -384,6 +592,17 @@ private:
     rvseg_ctx* map_ctx_ = nullptr;
     unsigned total_labels_ = 0;
     LocalMapStore store_;   // _cloud_results / _cloud_mtx (segmenter.h:94-108)
+    // queue layer
+    mutable std::mutex frame_mtx_;            // _frame_mtx: image and result queues
+    std::mutex cloud_processing_mtx_;         // _cloud_processing_mtx: the local-map queue
+    std::vector<float> camera_calib_;         // 21 floats per camera
+    std::vector<std::deque<QueuedFrame>> image_queues_;                               // _image_queues
+    std::vector<std::deque<std::pair<int, std::vector<float>>>> result_queues_;      // _result_queues
+    std::deque<LocalMap> local_map_queue_;                                            // _local_map_queue
+    std::mutex map_ctx_mtx_;
+    std::atomic<bool> running_{false};
+    std::thread rf_thread_, map_thread_;
+    std::string rf_error_, map_error_;
 };
 
 // DenseCRF2D as examples/dense_inference.cpp:83-107 drives it: the two image kernels, then map().

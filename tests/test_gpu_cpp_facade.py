@@ -57,3 +57,23 @@ def test_cpp_segmenter_facade(tmp_path, oracle, golden_dir):
     for l, C in enumerate((8, 9)):
         assert np.array_equal(fused_labels[l].view(np.int8), oracle.labels(want[off:off + N * C].reshape(N, C), C, 2, unknown=C - 1))
         off += N * C
+
+
+def test_cpp_segmenter_queue_layer(tmp_path, golden_dir):
+    """enqueueFrame / processFramesFromQueueInternalRF / onNewLocalMap / processMapFromQueue / start-stop / commInit +
+    gatherLabels (include/rvseg_segmenter.hpp; src/segmenter.cpp:245-304, 334-346, 434, 518-621): two cameras, 20 key
+    frames enqueued out of order, batched draining compared bit for bit with per-frame calls, skipped and postponed
+    maps, the worker threads, the RCCL gather at world size 1 (tests/cpp/segmenter_queue_test.cpp)."""
+    exe = str(tmp_path / "queue")
+    lib_dir = os.path.join(ROOT, "rovinasemanticsegmentation_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "segmenter_queue_test.cpp"), "-o", exe,
+                           "-L", lib_dir, "-lrvseg", "-lpthread", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    W, H = 160, 120
+    rgb, depth = synthetic.make_batch(1, W, H, holes=True)
+    (tmp_path / "rgb.u8").write_bytes(rgb[0].tobytes())
+    (tmp_path / "depth.u16").write_bytes(depth[0].tobytes())
+    r = subprocess.run([exe, os.path.join(golden_dir, "forest_multi.dat"), str(tmp_path / "rgb.u8"), str(tmp_path / "depth.u16")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "queue ok" in r.stdout
