@@ -130,7 +130,7 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency probe (profiling runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run oracle check of one batch frame")
     ap.add_argument("--extras", default="default",
-                    help="comma list of extra measurements outside the timed region (N=1 only): host,localmap,config5; "
+                    help="comma list of extra measurements outside the timed region (N=1 only): host,localmap,config5,train,deep; "
                          "'default' = all that the build supports, 'none' = skip")
     ap.add_argument("--rehearsal", action="store_true",
                     help="CPU rehearsal of the multi-rank protocol (gloo, no GPU, no hot path): launcher, sharding, "

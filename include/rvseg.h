@@ -344,8 +344,8 @@ void rvseg_schedule_default(rvseg_schedule *s);
 /* Applies to every later call on ctx (buffers of a schedule are allocated on first use). */
 rvseg_status rvseg_set_schedule(rvseg_ctx *ctx, const rvseg_schedule *s);
 
-/* What the last lattice build + mean field on this context ran with.  `planner_fallback` and `vertices` come from
- * the device with the build's status: they are valid once rvseg_poll_status(ctx, 1) has returned (host entry points:
+/* What the last lattice build + mean field on this context ran with.  `planner_fallback`, `vertices` and
+ * `longest_list` come from the device with the build's status: they are valid once rvseg_poll_status(ctx, 1) has returned (host entry points:
  * on return), -1 before.  A planner fall-back is not an error -- the same grid walks the lists the list-major way,
  * results are identical -- but it is slower, so it is reported here instead of staying silent. */
 typedef struct rvseg_schedule_info {
@@ -355,6 +355,7 @@ typedef struct rvseg_schedule_info {
     int32_t n_frames;            /* frames (1 for a cloud) and points per frame of that lattice                   */
     int32_t points_per_frame;
     int32_t vertices;            /* lattice vertices over all frames                                              */
+    int32_t longest_list;        /* entries of the longest vertex list: the longest ordered chain of the splat    */
     int32_t resident_blocks, resident_band, resident_chunk;   /* the resident schedule's shape (0 when not used)  */
     int32_t capacity_log2;       /* hash slots per frame                                                          */
 } rvseg_schedule_info;

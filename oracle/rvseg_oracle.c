@@ -289,35 +289,36 @@ float orc_acos_f32(float xf) {
     }
 }
 
-/* exp for expAndNormalize (densecrf.cpp:102; Eigen array().exp(), version unpinned).
- * n = rint(x*log2e); r = x - n*ln2 (two-part); degree-13 Taylor in Horner form; scale by 2^n. */
+/* exp for expAndNormalize (densecrf.cpp:102: `b.array().exp()`; Eigen is not in the tree, version unpinned: PARITY
+ * UNPINNED, build-owned definition).  Restates, as recollected, what Eigen 3's float packet path evaluates on an SSE
+ * build without FMA (pexp<Packet4f>, after Cephes expf): clamp to +-88.3762626647949, fx = floor(x*log2(e) + 0.5),
+ * two-step reduction by ln 2 = 0.693359375 - 2.12194440e-4, degree-5 polynomial (separately rounded multiply and add),
+ * y * x^2 + x + 1, exact scaling by 2^fx.  All in float; this file is compiled with -ffp-contract=off.  (Eigen sends the
+ * tail of a vector whose length is not a multiple of 4 through std::exp; here every class takes the packet formula.) */
 float orc_exp_f32(float xf) {
-    double x = (double)xf;
-    if (x != x) return xf;
-    if (x < -104.0) return 0.0f;
-    if (x > 88.8) return INFINITY;
-    double n = rint(x * 1.4426950408889634074);
-    /* fma() is part of the definition: IEEE-754 fixes its result, so libm / x86 FMA3 and the GPU's
-     * v_fma_f64 agree bit for bit (independent of -ffp-contract, which only governs a*b+c spelled
-     * with operators) */
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 0x1.ae64567f544e4p-26;            /* 1/11! */
-    p = fma(p, r, 0x1.27e4fb7789f5cp-22);        /* 1/10! */
-    p = fma(p, r, 0x1.71de3a556c734p-19);        /* 1/9!  */
-    p = fma(p, r, 0x1.a01a01a01a01ap-16);        /* 1/8!  */
-    p = fma(p, r, 0x1.a01a01a01a01ap-13);        /* 1/7!  */
-    p = fma(p, r, 0x1.6c16c16c16c17p-10);        /* 1/6!  */
-    p = fma(p, r, 0x1.1111111111111p-7);         /* 1/5!  */
-    p = fma(p, r, 0x1.5555555555555p-5);         /* 1/4!  */
-    p = fma(p, r, 0x1.5555555555555p-3);         /* 1/3!  */
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    uint64_t bits = (uint64_t)((int64_t)n + 1023) << 52;
-    double scale;
-    memcpy(&scale, &bits, 8);
-    return (float)(p * scale);
+    if (xf != xf) return xf;
+    float x = xf > 88.3762626647949f ? 88.3762626647949f : xf;
+    x = x < -88.3762626647949f ? -88.3762626647949f : x;
+    float fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    const float t = (float)(int)fx;
+    fx = t > fx ? t - 1.0f : t;
+    const float hi = fx * 0.693359375f;
+    const float lo = fx * -2.12194440e-4f;
+    x = x - hi;
+    x = x - lo;
+    const float z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z; y = y + x;
+    y = y + 1.0f;
+    union { int32_t i; float f; } sc;
+    sc.i = ((int32_t)fx + 127) << 23;
+    return y * sc.f;
 }
 
 /* =========================================================================================

@@ -67,7 +67,7 @@ class RvsegSchedule(C.Structure):
 
 class RvsegScheduleInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
-        "splat", "planner_fallback", "csr_path", "n_frames", "points_per_frame", "vertices", "resident_blocks",
+        "splat", "planner_fallback", "csr_path", "n_frames", "points_per_frame", "vertices", "longest_list", "resident_blocks",
         "resident_band", "resident_chunk", "capacity_log2")]
 
 

@@ -40,34 +40,37 @@ __device__ __forceinline__ float acos_f32_dev(float xf) {
     return (float)(2.0 * (df + w));
 }
 
-// exp for expAndNormalize (third-party/densecrf/src/densecrf.cpp:102): n = rint(x*log2e),
-// two-part ln2 reduction, degree-11 Taylor polynomial in Horner form, exact 2^n scaling.  The
-// fused multiply-adds are spelled out and part of the definition (IEEE-754 fixes fma, so
-// v_fma_f64 and the host's fma() agree); |r| <= ln2/2 leaves a truncation error below 1e-14.
-// Branch-free: the three special cases are selected at the end.
+// exp for expAndNormalize (third-party/densecrf/src/densecrf.cpp:102: `b.array().exp()`).  Eigen is not in the tree and its
+// version is unpinned, so the definition is build-owned (parity unpinned); it restates what Eigen 3's float packet
+// path (pexp<Packet4f>, Cephes expf) evaluates on an SSE build without FMA -- the reference's build -- in fp32:
+//   clamp to +-88.3762626647949; fx = floor(x * log2(e) + 0.5); x -= fx * 0.693359375; x -= fx * -2.12194440e-4;
+//   degree-5 polynomial in x (Horner, separately rounded multiply and add), y = poly * x^2 + x + 1; result = y * 2^fx.
+// Same sequence as oracle/rvseg_oracle.c:orc_exp_f32, operation for operation (the library is compiled with
+// -ffp-contract=off).  Round 1-2 used a double-precision Taylor chain here: 13 v_fma_f64 at half rate per class made
+// the fused update VALU bound.
 __device__ __forceinline__ float exp_f32_dev(float xf) {
-    const double x = (double)xf;
-    const double xc = x < -104.0 ? -104.0 : (x > 88.8 ? 88.8 : x);   // NaN falls through both compares
-    const double n = rint(xc * 1.4426950408889634074);
-    double r = __builtin_fma(-n, 6.93147180369123816490e-01, xc);
-    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 0x1.ae64567f544e4p-26;
-    p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = __builtin_fma(p, r, 0x1.1111111111111p-7);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-5);
-    p = __builtin_fma(p, r, 0x1.5555555555555p-3);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double scale = __longlong_as_double(((long long)n + 1023) << 52);
-    float res = (float)(p * scale);
-    res = x < -104.0 ? 0.0f : res;
-    res = x > 88.8 ? __int_as_float(0x7f800000) : res;
-    return x != x ? xf : res;
+    float x = xf > 88.3762626647949f ? 88.3762626647949f : xf;
+    x = x < -88.3762626647949f ? -88.3762626647949f : x;
+    float fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    const float t = (float)(int)fx;            // cvttps_epi32 + cvtepi32_ps: toward zero
+    fx = t > fx ? t - 1.0f : t;                // -> floor
+    const float hi = fx * 0.693359375f;
+    const float lo = fx * -2.12194440e-4f;
+    x = x - hi;
+    x = x - lo;
+    const float z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z; y = y + x;
+    y = y + 1.0f;
+    const float scale = __int_as_float(((int)fx + 127) << 23);
+    const float r = y * scale;
+    return xf != xf ? xf : r;
 }
 
 // Rows of C floats / d+1 ints are only 4-byte aligned; these vector types let the compiler fetch

@@ -693,6 +693,7 @@ vertex_len_kernel(LatticeDev L, unsigned* __restrict__ key, unsigned* __restrict
     const int M = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
     unsigned k = 0xFFFFFFFFu;  // unused ids sort to the end
     if (v < M) {
+        atomicMax(&L.counters[3], (int)(L.vend[v] - L.vstart[v]));   // the longest chain of the chunk (rvseg_last_schedule)
         const unsigned len = (L.vend[v] - L.vstart[v]) >> len_shift;
         const unsigned frame = (unsigned)(unsigned short)(L.vkeys[2 * (size_t)v + 1] >> 48);
         k = ((frame < 1023u ? frame : 1022u) << 22) | (0x3FFFFFu - (len < 0x3FFFFFu ? len : 0x3FFFFFu));
@@ -1233,7 +1234,7 @@ void launch_resident_plan(const LatticeDev& L, const SplatResidentDev& R, hipStr
     (void)hipMemsetAsync(R.flags, 0, 2 * sizeof(int), s);
     // dynamic LDS of the planner: tile sums [B][n_bands] words + the heavy table, inside the 64 KB a block gets by default
     const size_t t_bytes = (size_t)R.B * R.n_bands * 4;
-    const size_t fixed = 8192 + 4096 + RES_MAXB * RES_MAX_OWNV * 2 + 1024;
+    const size_t fixed = (size_t)RES_MAX_VERTS * 4 + (size_t)RES_MAX_VERTS * 2 + RES_MAXB * RES_MAX_OWNV * 2 + 1024;
     int heavy_cap = RES_HEAVY_MAX;
     while (heavy_cap > 8 && fixed + t_bytes + (size_t)heavy_cap * R.n_bands > 60000) heavy_cap -= 8;
     const size_t dyn = t_bytes + (size_t)heavy_cap * R.n_bands + 16;

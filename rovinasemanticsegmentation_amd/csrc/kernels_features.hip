@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256)
 prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ cbrt_tab,
             const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth,
             const float* __restrict__ calibA,  // n x 12: A = R*Kinv (row-major 9), t (3)
-            uint32_t* __restrict__ lab, float4* __restrict__ cloud, uint8_t* __restrict__ change, int n_frames) {
+            uint32_t* __restrict__ lab, float4* __restrict__ cloud, uint8_t* __restrict__ change, int n_frames,
+            uint2* __restrict__ lab2) {
     const size_t npix = (size_t)g.W * g.H;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= npix * (size_t)n_frames) return;
@@ -50,7 +51,14 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
         int a = (500 * (fX - fY) + 128 * (1 << 15) + (1 << 14)) >> 15;
         int b = (200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15;
         L = min(max(L, 0), 255); a = min(max(a, 0), 255); b = min(max(b, 0), 255);
-        lab[gid] = (uint32_t)L | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+        const uint32_t v = (uint32_t)L | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+        lab[gid] = v;
+        if (lab2) {   // {this pixel, the pixel below}: this thread writes its own top word and the bottom word of the row above
+            uint32_t* l2 = reinterpret_cast<uint32_t*>(lab2);
+            l2[2 * gid] = v;
+            if (y > 0) l2[2 * (gid - (size_t)g.W) + 1] = v;
+            if (y == g.H - 1) l2[2 * gid + 1] = v;
+        }
     }
     if (cloud) {
         const float* A = calibA + (size_t)frame * 12;
@@ -455,12 +463,12 @@ normal_feature_tiled_kernel(FrameGeom g, const float4* __restrict__ cloud_all, c
 
 // ---------------------------------------------------------------------------------------------
 void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
-                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s) {
+                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s, uint2* d_lab2) {
     LabCoeffs lc;
     for (int i = 0; i < 9; i++) lc.c[i] = lab.coeffs[i];
     const size_t total = (size_t)g.W * g.H * n;
     prep_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
-        g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, d_change, n);
+        g, lc, lab.gamma.as<uint16_t>(), lab.cbrt.as<uint16_t>(), d_rgb, d_depth, d_calibA, d_lab, d_cloud, d_change, n, d_lab ? d_lab2 : nullptr);
     RV_LAUNCHED("prep_kernel");
 }
 

@@ -291,13 +291,19 @@ rf_frames_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes,
 // = 2 LDS weight records + two 8-byte tap loads + ~25 integer ops -- the same arithmetic as phase B.
 // A node's two children are adjacent, so both are fetched together with the taps of the node's
 // own test: still one memory round trip per level.
+// COMPACT (round 3; PMC of the 16-byte-node version: texture addresser 92 % busy, 4 vector-memory instructions per
+// tree level): 8-byte nodes, so that BOTH children of a node arrive with one 16-byte load, and the row-pair Lab image
+// `lab2` ({lab(y, x), lab(y + 1, x)} per pixel), so that the 2 x 2 tap quad of a patch value is one 16-byte load as
+// well: two vector-memory instructions per level instead of four.  The arithmetic is unchanged.
 // =============================================================================================
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
 rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ nodes, const int32_t* __restrict__ roots,
                       const float* __restrict__ hist, int n_trees, const ResizeRow* __restrict__ rt, int rt_in_lds,
                       const uint32_t* __restrict__ lab_all, const uint16_t* __restrict__ depth_all,
                       const float4* __restrict__ cloud_all, const float* __restrict__ nfeat_all,
-                      float* __restrict__ low_all, int n_points_total) {
+                      float* __restrict__ low_all, int n_points_total, const uint32_t* __restrict__ nodes8,
+                      const uint32_t* __restrict__ lab2_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ResizeRow* rtl = rt;
     if (rt_in_lds) {
@@ -388,6 +394,30 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
         v = v < 0 ? 0 : (v > 255 ? 255 : v);
         return (float)v;
     };
+    // the same value from the row-pair image: one 16-byte load {top(x), bottom(x), top(x + 1), bottom(x + 1)}; a record's
+    // second row / column is the first one or its neighbour (pipeline_init: ofs1 = ofs or ofs + 1)
+    typedef uint32_t u32x4_p __attribute__((ext_vector_type(4), aligned(8)));
+    const uint32_t* lab2 = COMPACT ? lab2_all + 2 * (size_t)frame * W * H : nullptr;
+    auto patch_value_inside2 = [&](unsigned cell) -> float {   // cell = channel << 8 | dy << 4 | dx
+        const int c = (int)(cell >> 8) & 3, dy = (int)(cell >> 4) & 15, dx = (int)cell & 15;
+        const uint2 xr = *reinterpret_cast<const uint2*>(&myrt->x[dx]);
+        const uint2 yr = *reinterpret_cast<const uint2*>(&myrt->y[dy]);
+        const int sx0 = (int)(short)(xr.x & 0xffffu), ia0 = (int)(short)(xr.x >> 16), ia1 = (int)(short)(xr.y & 0xffffu);
+        const int ib0 = (int)(short)(yr.x >> 16), ib1 = (int)(short)(yr.y & 0xffffu);
+        const bool two = (int)(short)(xr.y >> 16) != sx0;
+        const int sy0 = (int)(short)(yr.x & 0xffffu);
+        const bool below = (int)(short)(yr.y >> 16) != sy0;
+        const u32x4_p q = *reinterpret_cast<const u32x4_p*>(lab2 + 2 * (lab_base + sy0 * W + sx0));
+        const int sh = 8 * c;
+        const uint32_t t0 = q.x, b0 = below ? q.y : q.x, t1 = two ? q.z : q.x, b1 = below ? (two ? q.w : q.y) : (two ? q.z : q.x);
+        const int a00 = (int)((t0 >> sh) & 255u), a01 = (int)((t1 >> sh) & 255u);
+        const int a10 = (int)((b0 >> sh) & 255u), a11 = (int)((b1 >> sh) & 255u);
+        const int r0 = a00 * ia0 + a01 * ia1;
+        const int r1 = a10 * ia0 + a11 * ia1;
+        int v = (((ib0 * (r0 >> 4)) >> 16) + ((ib1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        return (float)v;
+    };
     // strictly inside: the 8-byte tap load at column x0 + sx0 <= x0 + size - 1 must not be the image's last column
     const bool roi_inside = x0 >= 0 && y0 >= 0 && x0 + size < W && y0 + size <= H;
     const bool wave_inside = __ballot(valid && !roi_inside) == 0ull;
@@ -398,7 +428,21 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
     const int4* np = reinterpret_cast<const int4*>(nodes);
     for (int t = sub; t < n_trees; t += 4) {
         int row = 0;
-        if (valid) {
+        if (valid && COMPACT) {
+            const uint2* n8 = reinterpret_cast<const uint2*>(nodes8);
+            uint2 nd = n8[roots[t]];
+            while ((nd.y & 0xFFFFFu) != 0u) {
+                // both children in one load, in flight while the node's own test is evaluated
+                const u32x4_p ch = *reinterpret_cast<const u32x4_p*>(nodes8 + 2 * (size_t)(nd.y & 0xFFFFFu));
+                const unsigned kind = nd.y >> 30, cell = (nd.y >> 20) & 0x3FFu;
+                float v;
+                if (kind == 0u) v = wave_inside ? patch_value_inside2(cell) : patch_value((int)(((cell >> 8) & 3u) << 16 | ((cell >> 4) & 15u) << 8 | (cell & 15u)));
+                else v = kind == 1u ? depth_m : (kind == 2u ? height : nrm);
+                const bool go_left = v < __uint_as_float(nd.x);
+                nd = go_left ? make_uint2(ch.x, ch.y) : make_uint2(ch.z, ch.w);
+            }
+            row = (int)nd.x;
+        } else if (valid) {
             int4 nd = np[roots[t]];
             while (nd.z != 0) {
                 // both children travel while the node's own test is evaluated
@@ -452,9 +496,11 @@ rf_frames_lazy_kernel(FrameGeom g, ClassMap cm, const DeviceNode* __restrict__ n
 
 static bool n_trees_ok(int n_trees) { return n_trees >= 1 && n_trees <= 64; }   // leaf_rows[16] x 4 lanes per point
 
+bool rf_frames_wants_lab2(const DeviceForest& f) { return f.nodes8.p != nullptr && n_trees_ok(f.n_trees); }
+
 void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow* d_rt, const uint32_t* d_lab,
                       const uint16_t* d_depth, const float4* d_cloud, const float* d_nfeat, float* d_low,
-                      float* d_dump, uint8_t* d_valid, int n, hipStream_t s) {
+                      float* d_dump, uint8_t* d_valid, int n, hipStream_t s, const uint2* d_lab2) {
     ClassMap cm{};
     cm.S = f.sum_classes;
     cm.n_layers = f.n_layers;
@@ -476,9 +522,14 @@ void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow
     if (!d_dump && n_trees_ok(f.n_trees)) {
         const size_t rt_bytes = (size_t)g.rt_rows * sizeof(ResizeRow);
         const int in_lds = g.n_patch > 0 && rt_bytes <= 40 * 1024 ? 1 : 0;   // else the records come through L1
-        rf_frames_lazy_kernel<<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(
-            g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(), f.n_trees, d_rt, in_lds, d_lab, d_depth,
-            d_cloud, d_nfeat, d_low, total);
+        if (d_lab2 && rf_frames_wants_lab2(f))
+            rf_frames_lazy_kernel<true><<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(
+                g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(), f.n_trees, d_rt, in_lds, d_lab, d_depth,
+                d_cloud, d_nfeat, d_low, total, f.nodes8.as<uint32_t>(), reinterpret_cast<const uint32_t*>(d_lab2));
+        else
+            rf_frames_lazy_kernel<false><<<grid, dim3(256), in_lds ? rt_bytes : 0, s>>>(
+                g, cm, f.nodes.as<DeviceNode>(), f.roots.as<int32_t>(), f.hist.as<float>(), f.n_trees, d_rt, in_lds, d_lab, d_depth,
+                d_cloud, d_nfeat, d_low, total, nullptr, nullptr);
         RV_LAUNCHED("rf_frames_lazy_kernel");
         return;
     }

@@ -139,6 +139,36 @@ static rvseg_status upload_forest(rvseg_ctx* ctx) {
             }
         }
         RV_HIP(ctx, hipMemcpy(f.nodes.p, nodes.data(), nodes.size() * sizeof(DeviceNode), hipMemcpyHostToDevice));
+        // The frame kernel's 8-byte node: {threshold bits | leaf row, kind << 30 | channel << 28 | dy << 24 | dx << 20 | left}:
+        // a node's two children (adjacent in the array) arrive with ONE 16-byte load.  kind: 0 patch value, 1 depth,
+        // 2 height, 3 normal.  Possible while node indices fit 20 bits and patch cells 4 bits (r <= 16); larger models
+        // keep the 16-byte nodes.
+        dev_free(f.nodes8);
+        if (nodes.size() < (1u << 20) && r <= 16) {
+            const rvseg_params& pp = ctx->params;
+            int pos = n_patch;
+            const int pos_depth = pp.feature_depth ? pos++ : -1;
+            const int pos_height = pp.feature_height ? pos++ : -1;
+            const int pos_normal = pp.feature_normal ? pos++ : -1;
+            std::vector<uint32_t> n8(nodes.size() * 2);
+            for (size_t i = 0; i < nodes.size(); i++) {
+                const DeviceNode& dn = nodes[i];
+                if (dn.left == 0) { n8[2 * i] = (uint32_t)m.nodes[i].leaf_row; n8[2 * i + 1] = 0u; continue; }
+                uint32_t thr_bits;
+                std::memcpy(&thr_bits, &dn.threshold, 4);
+                uint32_t kind = 0, cell = 0;
+                if (dn.feature < n_patch) {
+                    const int c = dn.leaf_row >> 16, dy = (dn.leaf_row >> 8) & 255, dx = dn.leaf_row & 255;
+                    cell = ((uint32_t)c << 8) | ((uint32_t)dy << 4) | (uint32_t)dx;
+                } else {
+                    kind = dn.feature == pos_depth ? 1u : (dn.feature == pos_height ? 2u : (dn.feature == pos_normal ? 3u : 1u));
+                }
+                n8[2 * i] = thr_bits;
+                n8[2 * i + 1] = (kind << 30) | (cell << 20) | (uint32_t)dn.left;
+            }
+            if ((st = dev_alloc(ctx, f.nodes8, n8.size() * 4 + 16)) != RVSEG_OK) return st;
+            RV_HIP(ctx, hipMemcpy(f.nodes8.p, n8.data(), n8.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     RV_HIP(ctx, hipMemcpy(f.roots.p, m.roots.data(), m.roots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     RV_HIP(ctx, hipMemcpy(f.hist.p, hist.data(), hist.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -297,6 +327,7 @@ void rvseg_destroy(rvseg_ctx* ctx) {
     rvseg_comm_destroy(ctx);
     rvseg_pipeline_destroy(ctx);
     dev_free(ctx->forest.nodes);
+    dev_free(ctx->forest.nodes8);
     dev_free(ctx->forest.roots);
     dev_free(ctx->forest.hist);
     dev_free(ctx->lab.gamma);

@@ -22,7 +22,7 @@ struct LatticeDev {
     int* state;                  // per slot: EMPTY / LOCKED / FILLED
     unsigned long long* tkeys;   // per slot: 8 x int16 key (d coordinates .. frame)
     int* slot_to_id;
-    int* counters;               // [0] vertices M, [1] overflow flag
+    int* counters;               // [0] vertices M, [1] overflow flag, [2] (unused), [3] entries of the longest vertex list
     int* fstart;                 // n_frames + 1: first vertex id of each frame (ids are frame-contiguous)
     unsigned long long* vkeys;   // per vertex id: key
     int* offsets;                // P x (d+1): slot, later vertex id
@@ -54,7 +54,7 @@ struct LatticeDev {
 // changes from tile to tile, so the running sums live in LDS and a slot swaps its sum when its vertex changes.
 constexpr int RES_MAXB = 16;          // blocks per frame at most
 constexpr int RES_MAX_OWNV = 640;     // vertices a block can own (their running sums live in LDS): a 2 048-vertex frame on 4 blocks
-constexpr int RES_MAX_VERTS = 2048;   // vertices of a frame the planner handles
+constexpr int RES_MAX_VERTS = 4096;   // vertices of a frame the planner handles (= the counting-sort path's limit, CS_MCAP)
 constexpr int RES_MAX_BANDS = 512;
 struct SplatResidentDev {
     unsigned* tdesc;             // [n_frames][7][cap_tiles]: (first entry - frame's first entry) << 8 | entries (0..128)

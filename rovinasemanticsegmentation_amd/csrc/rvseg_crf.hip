@@ -30,7 +30,7 @@ struct CrfState {
     DevBuf val_a, val_b, tmp, q, qn, unary, feat, labels, val_a2, val_b2, tmp2, qn2;
     hipStream_t layer_stream = nullptr;       // the second layer's stream
     hipEvent_t layer_fork = nullptr, layer_join = nullptr;
-    // pinned read-back of a build: [0] M, [1] overflow, [2] filled, [3] frames the splat planner gave up on.
+    // pinned read-back of a build: [0] M, [1] overflow, [2] longest vertex list, [3] frames the splat planner gave up on.
     // Slot 0 (words 0..3) belongs to the asynchronous frame builds (consumed by crf_frames_status), slot 1 (words 4..7)
     // to the synchronous entry points -- a cloud or host CRF call on the same context must not overwrite a frame
     // build's status that nobody has polled yet.
@@ -38,6 +38,8 @@ struct CrfState {
     hipEvent_t counters_ev = nullptr;
     bool counters_pending = false;
     rvseg_schedule_info info{};    // what the last build ran with (rvseg_last_schedule)
+    int frame_vertices_seen = 0;   // vertices per frame of the last frame build whose status was read (0: none yet)
+    int pending_frames = 0;        // frames of the build whose status is pending
     bool info_async = false;       // info.vertices / planner_fallback still travel with the pending frame-build status
 };
 
@@ -104,14 +106,20 @@ static bool capacity_is_worst_case(const rvseg_ctx* ctx, int N, int d) {
 }
 
 // Does the resident band schedule pay for a chunk of this shape?  It wins where the list-major walk is bound by the
-// bytes it re-reads (many frames: 12 % faster at 64 frames of 640x480, 10 % at 16 frames of 1280x960, equal at 32 frames of
-// 640x480) and loses where the longest chain of one frame sets the time (a single frame, a cloud).  Both are functions
-// of the points per chunk and of the frame count, known on the host before the build is enqueued.
-static bool resident_pays(int n_frames, int N) {
-    return n_frames >= 2 && (long long)n_frames * N >= 12000000ll;
+// bytes it re-reads (many frames) and loses where a frame's chains set the time (few frames, a cloud) or where its
+// planner -- whose work grows with the vertices of a frame -- costs more than the splat saves.  Measured crossovers
+// (profiles/r03_schedule_sweep.json, step time of the whole frame path, 640x480 frames with holes): ~360 vertices per
+// frame (the flat synthetic scene): between 16 and 32 frames (resident 5.14 / 7.53 / 12.59 ms against 4.85 / 7.94 /
+// 13.97 at 16 / 32 / 64 frames); ~2 320 vertices per frame (the deep scene): between 32 and 64 frames (12.35 / 18.70
+// against 10.52 / 19.22).  A line through the two crossovers: resident from 5.6 M points + 4 900 points per vertex of a
+// frame.  The vertex count is a MEASURED quantity: that of the context's previous lattice build (read back with its
+// status); before any build has been seen, the flat scene's.
+static bool resident_pays(int n_frames, int N, int vertices_per_frame_seen) {
+    const long long vpf = vertices_per_frame_seen > 0 ? vertices_per_frame_seen : 360;
+    return n_frames >= 2 && (long long)n_frames * N >= 5600000ll + 4900ll * vpf;
 }
 
-static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe) {
+static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe, int vertices_per_frame_seen = 0) {
     if (d < 1 || d > 7) { ctx->err = "feature dimension must be in [1,7]"; return RVSEG_ERR_INVALID_ARG; }
     if (n_frames > 1022) { ctx->err = "at most 1022 frames per chunk (lower max_batch)"; return RVSEG_ERR_INVALID_ARG; }   // 10-bit frame field of the launch-order sort key
     const int Npad = (N + 3) / 4 * 4;
@@ -190,7 +198,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         const rvseg_schedule& sc = ctx->sched;
         // Worth it where the list-major walk is bound by the bytes it re-reads rather than by its longest chain
         // ("where it pays"): see resident_pays().  sched.splat = 2 forces it, 1 forbids it.
-        const bool wanted = sc.splat == 2 || (sc.splat == 0 && resident_pays(n_frames, N));
+        const bool wanted = sc.splat == 2 || (sc.splat == 0 && resident_pays(n_frames, N, vertices_per_frame_seen));
         const int chunk = sc.resident_chunk == 64 ? 64 : 128;
         const int capacity = resident_block_capacity(chunk);
         // one block per CU measured best (the tile loop is bound by its own barrier-coupled latencies, a second block on
@@ -302,6 +310,7 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     inf.n_frames = L.n_frames;
     inf.points_per_frame = L.N;
     inf.vertices = -1;
+    inf.longest_list = -1;
     inf.resident_blocks = b.resident_on ? b.resident.B : 0;
     inf.resident_band = b.resident_on ? b.resident.band_wb : 0;
     inf.resident_chunk = b.resident_on ? (1 << b.resident.chunk_log2) : 0;
@@ -313,7 +322,8 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
 // 1: synchronous entry points)
 static rvseg_status counters_readback(rvseg_ctx* ctx, CrfState* cs, const LatticeBufs& b, int slot, hipStream_t s) {
     int* h = cs->h_counters + 4 * slot;
-    RV_HIP(ctx, hipMemcpyAsync(h, b.dev.counters, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipMemcpyAsync(h, b.dev.counters, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    RV_HIP(ctx, hipMemcpyAsync(h + 2, b.dev.counters + 3, sizeof(int), hipMemcpyDeviceToHost, s));
     if (b.resident_on) RV_HIP(ctx, hipMemcpyAsync(h + 3, b.resident.flags, sizeof(int), hipMemcpyDeviceToHost, s));
     else h[3] = 0;   // (host write; no copy of this build touches the word)
     return RVSEG_OK;
@@ -327,6 +337,7 @@ static rvseg_status lattice_counters(rvseg_ctx* ctx, CrfState* cs, const Lattice
     const int* h = cs->h_counters + 4;
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     cs->info.vertices = h[0];
+    cs->info.longest_list = h[2];
     cs->info.planner_fallback = h[3];
     cs->info_async = false;
     return RVSEG_OK;
@@ -477,8 +488,10 @@ rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait) {
         RV_HIP(ctx, e);
     }
     cs->counters_pending = false;
+    if (cs->pending_frames > 0 && !cs->h_counters[1]) cs->frame_vertices_seen = cs->h_counters[0] / cs->pending_frames;
     if (cs->info_async) {   // no other lattice has been built on this context since
         cs->info.vertices = cs->h_counters[0];
+        cs->info.longest_list = cs->h_counters[2];
         cs->info.planner_fallback = cs->h_counters[3];
         cs->info_async = false;
     }
@@ -512,7 +525,7 @@ rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     if ((st = crf_frames_status(ctx, im, true)) != RVSEG_OK) return st;
     if (cs->lat.size() < 1) cs->lat.resize(1);
     LatticeBufs& lb = cs->lat[0];
-    if ((st = lattice_prepare(ctx, lb, 6, N, n, false)) != RVSEG_OK) return st;
+    if ((st = lattice_prepare(ctx, lb, 6, N, n, false, cs->frame_vertices_seen)) != RVSEG_OK) return st;
     FeatureSource fs{};
     fs.mode = 1; fs.cloud = im->cloud.as<float4>(); fs.rgb = d_rgb;
     fs.xyz_kernel = p.dcrf_xyz_kernel; fs.rgb_kernel = p.dcrf_rgb_kernel;
@@ -520,6 +533,7 @@ rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     if ((st = counters_readback(ctx, cs, lb, 0, s)) != RVSEG_OK) return st;
     RV_HIP(ctx, hipEventRecord(cs->counters_ev, s));
     cs->counters_pending = true;
+    cs->pending_frames = n;
     cs->info_async = true;
     return RVSEG_OK;
 }
@@ -827,6 +841,7 @@ rvseg_status rvseg_last_schedule(rvseg_ctx* ctx, rvseg_schedule_info* out) {
     std::memset(out, 0, sizeof(*out));
     out->planner_fallback = -1;
     out->vertices = -1;
+    out->longest_list = -1;
     if (!ctx->impl) return RVSEG_OK;
     Pipeline* im = reinterpret_cast<Pipeline*>(ctx->impl);
     if (im->crf) *out = im->crf->info;

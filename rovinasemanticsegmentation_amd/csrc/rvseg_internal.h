@@ -32,6 +32,7 @@ struct DeviceForest {
     int class_counts[RVSEG_MAX_LAYERS] = {}; // per layer
     int sum_classes = 0;                    // S
     DevBuf nodes;                           // DeviceNode[n_nodes]
+    DevBuf nodes8;                          // the same nodes in 8 bytes each (frame kernel), or empty: see upload_forest
     DevBuf roots;                           // int32[n_trees]
     DevBuf hist;                            // float[n_leaves * S] of the active mode
 };

@@ -40,8 +40,11 @@ struct UpsampleTables {
 };
 
 // ---- kernels_features.hip --------------------------------------------------------------------
+// d_lab2 (optional): the Lab image again with every pixel next to the one below it, {lab(y, x), lab(y + 1, x)} per
+// pixel: a bilinear tap quad of the patch resize is then ONE 16-byte load (kernels_rf.hip, rf_frames_lazy_kernel)
 void launch_prep(const FrameGeom& g, const LabTables& lab, const uint8_t* d_rgb, const uint16_t* d_depth,
-                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s);
+                 const float* d_calibA, uint32_t* d_lab, float4* d_cloud, uint8_t* d_change, int n, hipStream_t s,
+                 uint2* d_lab2 = nullptr);
 void launch_window_map(const FrameGeom& g, const float4* d_cloud, uint8_t* d_change, uint8_t* d_rect, int n, hipStream_t s);
 void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint8_t* d_rect, float* d_nfeat,
                            int n, hipStream_t s);
@@ -54,7 +57,9 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
 //   d_valid : optional n x (lh*lw) mask bytes
 void launch_rf_frames(const FrameGeom& g, const DeviceForest& f, const ResizeRow* d_rt, const uint32_t* d_lab,
                       const uint16_t* d_depth, const float4* d_cloud, const float* d_nfeat, float* d_low,
-                      float* d_dump, uint8_t* d_valid, int n, hipStream_t s);
+                      float* d_dump, uint8_t* d_valid, int n, hipStream_t s, const uint2* d_lab2 = nullptr);
+// true when the frame kernel can use the row-pair Lab image (8-byte nodes exist for this model)
+bool rf_frames_wants_lab2(const DeviceForest& f);
 // cv::resize to full resolution + pack [layer][y][x][class] (segmenter.cpp:380-431)
 void launch_upsample_pack(const FrameGeom& g, const DeviceForest& f, const UpsampleTables& t,
                           const float* d_low, float* d_post, int n, hipStream_t s);

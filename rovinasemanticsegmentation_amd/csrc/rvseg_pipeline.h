@@ -27,7 +27,7 @@ struct Pipeline {
     DevBuf resize_rows;
     UpsampleTables up;
     // per-chunk device buffers (grow-only, sized for up to max_batch frames)
-    DevBuf calibA, lab, cloud, change, rect, nfeat, low, post, marg, labels, in_rgb, in_depth, dump, valid;
+    DevBuf calibA, lab, lab2, cloud, change, rect, nfeat, low, post, marg, labels, in_rgb, in_depth, dump, valid;
     // pinned staging for the per-frame A = R*Kinv, t.  The device entry point returns without
     // synchronising, so a slot may only be rewritten once the copy that read it has run: a small ring,
     // each slot guarded by an event recorded behind its H2D copy

@@ -113,7 +113,7 @@ rvseg_status pipeline_init(rvseg_ctx* ctx) {
 
 static void pipeline_free(Pipeline* im) {
     DevBuf* all[] = {&im->resize_rows, &im->up.xofs, &im->up.ax0, &im->up.ax1, &im->up.yofs, &im->up.ay0, &im->up.ay1,
-                     &im->calibA, &im->lab, &im->cloud, &im->rect, &im->nfeat, &im->low, &im->post, &im->marg,
+                     &im->calibA, &im->lab, &im->lab2, &im->cloud, &im->rect, &im->nfeat, &im->low, &im->post, &im->marg,
                      &im->labels, &im->in_rgb, &im->in_depth, &im->dump, &im->valid, &im->change};
     for (DevBuf* b : all) dev_free(*b);
     for (int i = 0; i < Pipeline::CALIB_RING; i++) {
@@ -202,6 +202,8 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     rvseg_status st;
     const bool need_cloud = p.feature_height || p.feature_normal || p.use_dense_crf;
     if (p.feature_color_patch && (st = dev_reserve(ctx, im->lab, npix * 4 * n)) != RVSEG_OK) return st;
+    const bool use_lab2 = p.feature_color_patch && rf_frames_wants_lab2(f);
+    if (use_lab2 && (st = dev_reserve(ctx, im->lab2, npix * 8 * n + 16)) != RVSEG_OK) return st;
     if (need_cloud && (st = dev_reserve(ctx, im->cloud, npix * 16 * n)) != RVSEG_OK) return st;
     if (p.feature_normal) {
         if ((st = dev_reserve(ctx, im->rect, npix * n)) != RVSEG_OK) return st;
@@ -216,7 +218,8 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     }
     timer_mark(ctx, "prep", s);
     launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
-                need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s);
+                need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s,
+                use_lab2 ? im->lab2.as<uint2>() : nullptr);
     bool forked = false;
     if (p.use_dense_crf && ctx->sched.overlap_build) {
         // fork: the lattice build runs on the side stream while this stream extracts features and walks the forest
@@ -251,7 +254,7 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     }
     timer_mark(ctx, "rf_frames", s);
     launch_rf_frames(g, f, im->resize_rows.as<ResizeRow>(), im->lab.as<uint32_t>(), d_depth, im->cloud.as<float4>(),
-                     im->nfeat.as<float>(), im->low.as<float>(), nullptr, nullptr, n, s);
+                     im->nfeat.as<float>(), im->low.as<float>(), nullptr, nullptr, n, s, use_lab2 ? im->lab2.as<uint2>() : nullptr);
     timer_mark(ctx, "upsample_pack", s);
     launch_upsample_pack(g, f, im->up, im->low.as<float>(), post, n, s);
     if (p.use_dense_crf) {

@@ -27,7 +27,39 @@ def make_calib(W=640, H=480):
     return np.concatenate([Kinv.ravel(), R.ravel(), t]).astype(np.float32)
 
 
-def make_frame(index=0, W=640, H=480, holes=False, seed=1234):
+def make_deep_frame(index=0, W=640, H=480, holes=False, seed=1234):
+    """A scene with a deep range and textured colour: a ground plane receding from 1 m to 10 m, box-shaped
+    obstacles, slowly varying saturated colours.  The Segmenter's CRF kernel (xyz * 0.5, rgb * 4) gives such a frame
+    1 500+ lattice vertices instead of the ~300 of `make_frame` -- the regime of a real photo (1 660-2 240
+    on the reference's im2.ppm with a 1-10 m depth)."""
+    rng = np.random.default_rng(seed + 7919 * (index + 1))
+    ys, xs = np.mgrid[0:H, 0:W]
+    fy = ys / float(H)
+    depth = 10000.0 - 9000.0 * fy ** 0.7
+    for k in range(6):   # obstacles: columns of the image 0.6 - 2.4 m in front of the ground behind them
+        x0 = int((0.08 + 0.15 * k + 0.02 * ((index + k) % 3)) * W)
+        w = int(0.07 * W)
+        top = int((0.15 + 0.1 * ((k + index) % 4)) * H)
+        sel = (xs >= x0) & (xs < x0 + w) & (ys >= top)
+        depth = np.where(sel, np.maximum(900.0, depth - (600.0 + 300.0 * k)), depth)
+    depth = depth + rng.integers(-5, 6, size=(H, W))
+    ph = 0.7 * index
+    r = 128 + 100 * np.sin(xs * (50.0 / W) * 0.25 + ph)
+    g = 128 + 100 * np.sin(ys * (37.0 / H) * 0.35 + 1.3 + ph)
+    b = 128 + 100 * np.sin((xs / float(W) + ys / float(H)) * 9.0 + 2.1 - ph)
+    rgb = np.stack([r, g, b], -1) + rng.integers(-8, 9, size=(H, W, 3))
+    rgb = np.clip(rgb, 0, 255).astype(np.uint8)
+    depth = np.clip(depth, 500, 15000).astype(np.uint16)
+    if holes:
+        hole = rng.random((H // 8 + 1, W // 8 + 1)) < 0.10
+        hole = np.kron(hole, np.ones((8, 8), bool))[:H, :W]
+        depth[hole] = 0
+    return rgb, depth
+
+
+def make_frame(index=0, W=640, H=480, holes=False, seed=1234, scene="flat"):
+    if scene == "deep":
+        return make_deep_frame(index, W, H, holes, seed)
     rng = np.random.default_rng(seed + index)
     ys, xs = np.mgrid[0:H, 0:W]
     base = np.array([[180, 60, 50], [60, 170, 70], [50, 80, 190]], np.float64)
@@ -46,11 +78,11 @@ def make_frame(index=0, W=640, H=480, holes=False, seed=1234):
     return rgb, depth
 
 
-def make_batch(n, W=640, H=480, holes=False, seed=1234, start=0):
+def make_batch(n, W=640, H=480, holes=False, seed=1234, start=0, scene="flat"):
     rgb = np.empty((n, H, W, 3), np.uint8)
     depth = np.empty((n, H, W), np.uint16)
     for i in range(n):
-        rgb[i], depth[i] = make_frame(start + i, W, H, holes, seed)
+        rgb[i], depth[i] = make_frame(start + i, W, H, holes, seed, scene)
     return rgb, depth
 
 

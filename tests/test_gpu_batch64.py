@@ -68,3 +68,45 @@ def test_batch64_headline_config_matches_oracle_and_single_frame_runs(gpu_ctx_fa
         out = one_ctx.segment_frames(rgb[i:i + 1], depth[i:i + 1], calib, want_posteriors=False)
         assert np.array_equal(out["labels"][0].ravel(), lab[i]), i
         assert np.array_equal(out["marginals"][0], marg[i]), i
+
+
+def test_deep_scene_many_vertices_default_schedule(gpu_ctx_factory, oracle):
+    """A scene with a 1-10 m depth range and textured colour: ~2 300 lattice vertices per frame instead of the ~350 of
+    the flat scene every other test uses (the regime of a real photo).  8 frames of 640x480 through the host entry with
+    default parameters: the default hash capacity (2^12 slots per frame) overflows once, is raised and the chunk
+    repeated; the schedule is the library's own choice (no forcing) and is reported; every frame bit-exact against the
+    oracle."""
+    import rovinasemanticsegmentation_amd as rv
+    n = 8
+    blob = synthetic.make_forest_bytes(seed=7, n_trees=4, leaves_per_tree=1 << 12, max_depth=20, single_classes=C, layer_classes=(8, 9))
+    rgb, depth = synthetic.make_batch(n, W, H, holes=True, scene="deep")
+    calib = synthetic.make_calib(W, H)
+    kw = dict(multi_layer=0, use_dense_crf=1, dcrf_iterations=5, label_mode=rv.capi.LABEL_CRF, unknown_label=[8])
+    ctx = gpu_ctx_factory(max_batch=n, **kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib, want_posteriors=False)
+    info = ctx.last_schedule()
+    assert info["vertices"] >= n * 1500 and info["capacity_log2"] >= 13, info      # many vertices; the capacity was raised
+    assert info["splat"] == "list-major" and info["planner_fallback"] == 0 and info["csr_path"] == 1, info
+    forest = oracle.Forest(blob)
+    p = oracle.default_params(dcrf_iterations=5)
+
+    def one(i):
+        return oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
+
+    with ThreadPoolExecutor(max(1, min(os.cpu_count() or 1, 16))) as ex:
+        want = list(ex.map(one, range(n)))
+    for i in range(n):
+        _, wm, wl = want[i]
+        assert np.array_equal(out["labels"][i].ravel(), wl), i
+        assert np.abs(out["marginals"][i] - wm).max() <= TOL, i
+        assert np.array_equal(out["marginals"][i], wm), i
+    # the same frames under the resident band schedule (forced): its planner handles > 2 048 vertices per frame
+    ctx2 = gpu_ctx_factory(max_batch=4, lattice_capacity_log2=13, schedule=dict(splat=2, resident_blocks=4), **kw)
+    ctx2.forest_load(blob)
+    out2 = ctx2.segment_frames(rgb[:4], depth[:4], calib, want_posteriors=False)
+    info2 = ctx2.last_schedule()
+    assert info2["splat"] == "resident" and info2["planner_fallback"] == 0, info2
+    for i in range(4):
+        assert np.array_equal(out2["marginals"][i], out["marginals"][i]), i
+        assert np.array_equal(out2["labels"][i], out["labels"][i]), i

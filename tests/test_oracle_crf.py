@@ -126,17 +126,18 @@ def test_padding_lanes_are_inserted(oracle):
 
 
 def test_exp_close_to_libm(oracle):
+    """The build-owned exp (Eigen's float packet formula after Cephes expf, fp32 throughout): within 2 ulp of the
+    correctly rounded value over the softmax's argument range, exact at 0, zero below the clamp."""
     rng = np.random.default_rng(3)
-    xs = np.concatenate([-rng.random(3000) * 30, [0.0, -1e-8, -87.0, -100.0, -103.9, -104.5, -1000.0]]).astype(np.float32)
-    bad = 0
+    xs = np.concatenate([-rng.random(3000) * 30, -rng.random(500) * 87, [0.0, -1e-8, -50.0, -87.0]]).astype(np.float32)
+    worst = 0.0
     for x in xs:
         got = np.float32(oracle.exp_f32(x))
-        want = np.float32(np.exp(np.float64(x)))
-        if got != want:
-            bad += 1
-            assert abs(float(got) - float(want)) <= np.spacing(max(want, np.float32(1e-45)))
-    assert bad <= 3
-    assert oracle.exp_f32(0.0) == 1.0 and oracle.exp_f32(-1000.0) == 0.0
+        want = np.exp(np.float64(x))
+        worst = max(worst, abs(float(got) - want) / float(np.spacing(np.float32(want))))
+    assert worst <= 2.0, worst
+    assert oracle.exp_f32(0.0) == 1.0 and oracle.exp_f32(-1000.0) == 0.0 and oracle.exp_f32(-88.5) == 0.0
+    assert oracle.exp_f32(1.0) == np.float32(np.e) or abs(float(oracle.exp_f32(1.0)) - np.e) < 3e-7
 
 
 def test_exp_and_normalize(oracle):
