@@ -200,6 +200,13 @@ rvseg_status rvseg_extract_features(rvseg_ctx *ctx, const uint8_t *rgb, const ui
 rvseg_status rvseg_segment_frames(rvseg_ctx *ctx, int32_t n_frames, const uint8_t *rgb,
                                   const uint16_t *depth_mm, const float *calib, float *posteriors_out,
                                   float *marginals_out, int8_t *labels_out);
+/* Page-locks a caller buffer (hipHostRegister) / releases it.  rvseg_segment_frames recognises page-locked input and
+ * output buffers (registered here, or allocated with hipHostMalloc) and lets the copy engines read / write them directly:
+ * without it every output crosses the host memory twice (pinned staging, then the caller's pageable buffer), which
+ * bounds a call that returns marginals -- 11 MB per frame, src/segmenter.cpp:413-434 -- at the host's memcpy rate.
+ * Register once, reuse the buffers across calls (registration costs milliseconds). */
+rvseg_status rvseg_host_register(void *p, size_t bytes);
+rvseg_status rvseg_host_unregister(void *p);
 rvseg_status rvseg_segment_frames_device(rvseg_ctx *ctx, int32_t n_frames, const uint8_t *d_rgb,
                                          const uint16_t *d_depth_mm, const float *calib,
                                          float *d_posteriors_out, float *d_marginals_out,

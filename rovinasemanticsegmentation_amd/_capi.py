@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librvseg.so")
+# RVSEG_LIBRARY: another build of the library (A/B timing of kernel variants on one GPU box); the product default is the
+# in-tree librvseg.so
+LIB_PATH = os.environ.get("RVSEG_LIBRARY") or os.path.join(_HERE, "librvseg.so")
 
 RVSEG_MAX_LAYERS = 8
 
@@ -31,6 +33,7 @@ SYMBOLS = [
     "rvseg_comm_unique_id", "rvseg_comm_init", "rvseg_comm_destroy", "rvseg_gather_frames",
     "rvseg_schedule_default", "rvseg_set_schedule", "rvseg_last_schedule",
     "rvseg_forest_train_result", "rvseg_forest_train_frames",
+    "rvseg_host_register", "rvseg_host_unregister",
 ]
 
 
@@ -138,6 +141,8 @@ def lib():
     L.rvseg_forest_train_result.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rvseg_forest_train_frames.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, i32, C.POINTER(RvsegTrainParams), vp, C.c_size_t,
                                             C.POINTER(C.c_size_t), C.POINTER(i32)]
+    L.rvseg_host_register.argtypes = [vp, C.c_size_t]
+    L.rvseg_host_unregister.argtypes = [vp]
     L.rvseg_comm_unique_id.argtypes = [vp]
     L.rvseg_comm_init.argtypes = [vp, i32, i32, vp]
     L.rvseg_comm_destroy.argtypes = [vp]

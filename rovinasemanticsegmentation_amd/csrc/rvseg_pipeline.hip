@@ -349,6 +349,15 @@ rvseg_status pinned_reserve(rvseg_ctx* ctx, void*& p, size_t& cap, size_t bytes)
     return RVSEG_OK;
 }
 
+// is p page-locked host memory (hipHostMalloc / hipHostRegister, e.g. through rvseg_host_register)?  Then the DMA engines
+// reach it directly and the pinned staging copy is skipped.
+bool is_pinned_host(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // pageable memory is unknown to the runtime
+    return at.type == hipMemoryTypeHost;
+}
+
 rvseg_status stage_init(rvseg_ctx* ctx, HostStage& hs) {
     if (hs.ready) return RVSEG_OK;
     RV_HIP(ctx, hipStreamCreateWithFlags(&hs.s_in, hipStreamNonBlocking));
@@ -380,6 +389,11 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
     const size_t npix = (size_t)g.W * g.H;
     const size_t S = (size_t)ctx->forest.sum_classes, L = (size_t)ctx->forest.n_layers;
     const bool want_marg = marginals_out && ctx->params.use_dense_crf;
+    // page-locked caller buffers are read / written by the copy engines directly (no staging copy on the host):
+    // the 11 MB of marginals per frame otherwise cross the host memory twice, which bounds the call at ~10 GB/s
+    const bool in_pinned = is_pinned_host(rgb) && is_pinned_host(depth_mm);
+    const bool post_pinned = is_pinned_host(posteriors_out), marg_pinned = want_marg && is_pinned_host(marginals_out),
+               lab_pinned = is_pinned_host(labels_out);
     hipStream_t s = ctx->stream;
     // chunk size: at most max_batch, and small enough that a call has a few chunks to overlap
     const int chunk = std::max(1, std::min(ctx->params.max_batch, std::max(8, (n_frames + 3) / 4)));
@@ -391,9 +405,9 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
         const int slot = c % HostStage::SLOTS, n = chunk_n(c);
         const size_t start = (size_t)c * chunk;
         RV_HIP(ctx, hipEventSynchronize(hs.ev_out[slot]));
-        if (posteriors_out) host_copy(posteriors_out + start * npix * S, hs.h_post[slot], npix * S * 4 * n);
-        if (want_marg) host_copy(marginals_out + start * npix * S, hs.h_marg[slot], npix * S * 4 * n);
-        if (labels_out) host_copy(labels_out + start * npix * L, hs.h_lab[slot], npix * L * n);
+        if (posteriors_out && !post_pinned) host_copy(posteriors_out + start * npix * S, hs.h_post[slot], npix * S * 4 * n);
+        if (want_marg && !marg_pinned) host_copy(marginals_out + start * npix * S, hs.h_marg[slot], npix * S * 4 * n);
+        if (labels_out && !lab_pinned) host_copy(labels_out + start * npix * L, hs.h_lab[slot], npix * L * n);
         return RVSEG_OK;
     };
     auto drain = [&]() { (void)hipStreamSynchronize(hs.s_in); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(hs.s_out); };
@@ -412,24 +426,30 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
         const int slot = c % HostStage::SLOTS, n = chunk_n(c);
         const size_t start = (size_t)c * chunk;
         // staging + device buffers of this slot (grow only; the slot's previous chunk c - 2 has been retired)
-        if ((st = pinned_reserve(ctx, hs.h_rgb[slot], hs.c_rgb[slot], npix * 3 * n)) != RVSEG_OK ||
-            (st = pinned_reserve(ctx, hs.h_depth[slot], hs.c_depth[slot], npix * 2 * n)) != RVSEG_OK ||
+        if ((!in_pinned && ((st = pinned_reserve(ctx, hs.h_rgb[slot], hs.c_rgb[slot], npix * 3 * n)) != RVSEG_OK ||
+                            (st = pinned_reserve(ctx, hs.h_depth[slot], hs.c_depth[slot], npix * 2 * n)) != RVSEG_OK)) ||
             (st = dev_reserve(ctx, hs.d_rgb[slot], npix * 3 * n)) != RVSEG_OK ||
             (st = dev_reserve(ctx, hs.d_depth[slot], npix * 2 * n)) != RVSEG_OK) { drain(); return st; }
         const bool need_post_dev = posteriors_out != nullptr;
-        if (need_post_dev && ((st = pinned_reserve(ctx, hs.h_post[slot], hs.c_post[slot], npix * S * 4 * n)) != RVSEG_OK ||
+        if (need_post_dev && ((!post_pinned && (st = pinned_reserve(ctx, hs.h_post[slot], hs.c_post[slot], npix * S * 4 * n)) != RVSEG_OK) ||
                               (st = dev_reserve(ctx, hs.d_post[slot], npix * S * 4 * n)) != RVSEG_OK)) { drain(); return st; }
-        if (want_marg && ((st = pinned_reserve(ctx, hs.h_marg[slot], hs.c_marg[slot], npix * S * 4 * n)) != RVSEG_OK ||
+        if (want_marg && ((!marg_pinned && (st = pinned_reserve(ctx, hs.h_marg[slot], hs.c_marg[slot], npix * S * 4 * n)) != RVSEG_OK) ||
                           (st = dev_reserve(ctx, hs.d_marg[slot], npix * S * 4 * n)) != RVSEG_OK)) { drain(); return st; }
-        if (labels_out && ((st = pinned_reserve(ctx, hs.h_lab[slot], hs.c_lab[slot], npix * L * n)) != RVSEG_OK ||
+        if (labels_out && ((!lab_pinned && (st = pinned_reserve(ctx, hs.h_lab[slot], hs.c_lab[slot], npix * L * n)) != RVSEG_OK) ||
                            (st = dev_reserve(ctx, hs.d_lab[slot], npix * L * n)) != RVSEG_OK)) { drain(); return st; }
         // 1. caller's pageable buffers -> pinned (host threads; the GPU is busy with chunk c - 1 meanwhile)
-        host_copy(hs.h_rgb[slot], rgb + start * npix * 3, npix * 3 * n);
-        host_copy(hs.h_depth[slot], depth_mm + start * npix, npix * 2 * n);
+        const void* src_rgb = rgb + start * npix * 3;
+        const void* src_depth = depth_mm + start * npix;
+        if (!in_pinned) {
+            host_copy(hs.h_rgb[slot], src_rgb, npix * 3 * n);
+            host_copy(hs.h_depth[slot], src_depth, npix * 2 * n);
+            src_rgb = hs.h_rgb[slot];
+            src_depth = hs.h_depth[slot];
+        }
         // 2. H2D on the input stream, after the compute of chunk c - 2 (the last reader of these device buffers)
         if (c >= HostStage::SLOTS) RV_HIP(ctx, hipStreamWaitEvent(hs.s_in, hs.ev_done[slot], 0));
-        RV_HIP(ctx, hipMemcpyAsync(hs.d_rgb[slot].p, hs.h_rgb[slot], npix * 3 * n, hipMemcpyHostToDevice, hs.s_in));
-        RV_HIP(ctx, hipMemcpyAsync(hs.d_depth[slot].p, hs.h_depth[slot], npix * 2 * n, hipMemcpyHostToDevice, hs.s_in));
+        RV_HIP(ctx, hipMemcpyAsync(hs.d_rgb[slot].p, src_rgb, npix * 3 * n, hipMemcpyHostToDevice, hs.s_in));
+        RV_HIP(ctx, hipMemcpyAsync(hs.d_depth[slot].p, src_depth, npix * 2 * n, hipMemcpyHostToDevice, hs.s_in));
         RV_HIP(ctx, hipEventRecord(hs.ev_in[slot], hs.s_in));
         // 3. compute: after its inputs arrived and after the D2H of chunk c - 2 released the output buffers
         RV_HIP(ctx, hipStreamWaitEvent(s, hs.ev_in[slot], 0));
@@ -451,13 +471,29 @@ rvseg_status rvseg_segment_frames(rvseg_ctx* ctx, int32_t n_frames, const uint8_
         RV_HIP(ctx, hipEventRecord(hs.ev_done[slot], s));
         // 4. D2H on the output stream
         RV_HIP(ctx, hipStreamWaitEvent(hs.s_out, hs.ev_done[slot], 0));
-        if (posteriors_out) RV_HIP(ctx, hipMemcpyAsync(hs.h_post[slot], hs.d_post[slot].p, npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
-        if (want_marg) RV_HIP(ctx, hipMemcpyAsync(hs.h_marg[slot], hs.d_marg[slot].p, npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
-        if (labels_out) RV_HIP(ctx, hipMemcpyAsync(hs.h_lab[slot], hs.d_lab[slot].p, npix * L * n, hipMemcpyDeviceToHost, hs.s_out));
+        if (posteriors_out) RV_HIP(ctx, hipMemcpyAsync(post_pinned ? (void*)(posteriors_out + start * npix * S) : hs.h_post[slot], hs.d_post[slot].p,
+                                                       npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
+        if (want_marg) RV_HIP(ctx, hipMemcpyAsync(marg_pinned ? (void*)(marginals_out + start * npix * S) : hs.h_marg[slot], hs.d_marg[slot].p,
+                                                  npix * S * 4 * n, hipMemcpyDeviceToHost, hs.s_out));
+        if (labels_out) RV_HIP(ctx, hipMemcpyAsync(lab_pinned ? (void*)(labels_out + start * npix * L) : hs.h_lab[slot], hs.d_lab[slot].p,
+                                                   npix * L * n, hipMemcpyDeviceToHost, hs.s_out));
         RV_HIP(ctx, hipEventRecord(hs.ev_out[slot], hs.s_out));
         // 5. hand chunk c - 1 to the caller while chunk c runs (its build status was checked by run_chunk above)
         if (c >= 1 && (st = retire(c - 1)) != RVSEG_OK) { drain(); return st; }
     }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return RVSEG_ERR_INVALID_ARG;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorHostMemoryAlreadyRegistered ? RVSEG_OK : RVSEG_ERR_HIP; }
+    return RVSEG_OK;
+}
+
+rvseg_status rvseg_host_unregister(void* p) {
+    if (!p) return RVSEG_ERR_INVALID_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return RVSEG_ERR_HIP; }
     return RVSEG_OK;
 }
 

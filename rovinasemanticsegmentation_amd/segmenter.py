@@ -188,8 +188,40 @@ class Context:
         return feat[:n.value].copy(), xv[:n.value].copy(), yv[:n.value].copy()
 
     # ---- whole path --------------------------------------------------------------------------
-    def segment_frames(self, rgb, depth, calib, want_posteriors=True, want_marginals=None, want_labels=True):
+    def host_buffers(self, n, want_posteriors=True, want_marginals=None, want_labels=True):
+        """Page-locked (rvseg_host_register) in / out buffers for calls of n frames: pass them to segment_frames(out=...)
+        and reuse them across calls; free with release_host_buffers."""
         p = self.params
+        cc = self.forest_info()["class_counts"]
+        S, Lc, N = sum(cc), len(cc), p.width * p.height
+        if want_marginals is None:
+            want_marginals = bool(p.use_dense_crf)
+        bufs = {"rgb": np.empty((n, p.height, p.width, 3), np.uint8), "depth": np.empty((n, p.height, p.width), np.uint16),
+                "posteriors": np.empty((n, S * N), np.float32) if want_posteriors else None,
+                "marginals": np.empty((n, S * N), np.float32) if want_marginals else None,
+                "labels": np.empty((n, Lc, p.height, p.width), np.int8) if want_labels else None, "class_counts": cc}
+        for k in ("rgb", "depth", "posteriors", "marginals", "labels"):
+            if bufs[k] is not None:
+                st = self.L.rvseg_host_register(_ptr(bufs[k]), bufs[k].nbytes)
+                if st != capi.OK:
+                    raise capi.RvsegError(st, "rvseg_host_register failed")
+        return bufs
+
+    def release_host_buffers(self, bufs):
+        for k in ("rgb", "depth", "posteriors", "marginals", "labels"):
+            if bufs.get(k) is not None:
+                self.L.rvseg_host_unregister(_ptr(bufs[k]))
+
+    def segment_frames(self, rgb, depth, calib, want_posteriors=True, want_marginals=None, want_labels=True, out=None):
+        """out: buffers from host_buffers() (page-locked): results land there without a staging copy; rgb / depth may be
+        out["rgb"] / out["depth"] themselves."""
+        p = self.params
+        if out is not None:
+            n = rgb.shape[0]
+            calib = np.ascontiguousarray(np.broadcast_to(np.asarray(calib, np.float32).reshape(-1, 21), (n, 21)))
+            capi.check(self.h, self.L.rvseg_segment_frames(self.h, n, _ptr(rgb), _ptr(depth), _ptr(calib), _ptr(out["posteriors"]),
+                                                           _ptr(out["marginals"]), _ptr(out["labels"])))
+            return out
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16)
         n = rgb.shape[0]

@@ -197,3 +197,32 @@ def test_lazy_walk_touches_every_feature(gpu_ctx_factory, oracle):
         want, P = oracle.rf_frame(p, forest, 1, rgb[i], depth[i], calib)
         assert P > 1000
         assert np.array_equal(out["posteriors"][i], want), i
+
+
+def test_host_entry_with_page_locked_buffers_equals_the_staged_path(gpu_ctx_factory):
+    """rvseg_host_register'ed in / out buffers (the copy engines write the caller's memory directly) against ordinary
+    pageable numpy buffers (pinned staging ring inside the library): identical outputs, three chunks per call."""
+    W, H = 160, 120
+    blob = synthetic.make_forest_bytes(seed=12, n_trees=4, leaves_per_tree=256, max_depth=12)
+    rgb, depth = synthetic.make_batch(20, W, H, holes=True)
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(width=W, height=H, use_dense_crf=1, dcrf_iterations=2, label_mode=1, max_batch=8)
+    ctx.forest_load(blob)
+    want = ctx.segment_frames(rgb, depth, calib)
+    bufs = ctx.host_buffers(20)
+    try:
+        bufs["rgb"][...] = rgb
+        bufs["depth"][...] = depth
+        for k in ("posteriors", "marginals", "labels"):
+            bufs[k].fill(0)
+        got = ctx.segment_frames(bufs["rgb"], bufs["depth"], calib, out=bufs)
+        for k in ("posteriors", "marginals", "labels"):
+            assert np.array_equal(got[k], want[k]), k
+        # mixed: page-locked outputs, pageable inputs
+        for k in ("posteriors", "marginals", "labels"):
+            bufs[k].fill(0)
+        got = ctx.segment_frames(rgb, depth, calib, out=bufs)
+        for k in ("posteriors", "marginals", "labels"):
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        ctx.release_host_buffers(bufs)
