@@ -776,10 +776,17 @@ static_assert(SPLAT_RE % SPLAT_RR == 0, "ring positions are compile-time: the ro
 // product is 0 * x = +0 by itself (no select), and the row address needs no per-frame split.
 // One item of the list-major walk: G vertices of one frame, whole lists.  The kernel below runs one item per block; the
 // resident kernel falls back to a loop over these items when its planner gave up.
-template <int MODE, int CC, bool FULL, int GV, bool FAST>
+// NH = entries per producer lane and tile: 1 (64-entry tiles, rings of 16 / 8 tiles) or 2 (128-entry tiles, rings of 8 / 4:
+// the same look-ahead in time).  A launch whose time is its longest chain (a single frame, a cloud, chunks of <= 16
+// frames) pays the per-tile costs -- barrier, table reads, the wait for the first product row -- per 128 dependent adds
+// instead of per 64 with NH = 2.
+template <int MODE, int CC, bool FULL, int GV, bool FAST, int NH = 1>
 __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const ValueView& src, int C, int c0, int n_store, float* __restrict__ values,
-                                                 unsigned item, float (*prod)[GV][CC][68]) {
+                                                 unsigned item, float (*prod)[GV][CC][64 * NH + 4]) {
     constexpr int G = GV;
+    constexpr int TE = 64 * NH;                       // entries per tile
+    constexpr int RE_ = NH == 2 ? 8 : SPLAT_RE, RR_ = NH == 2 ? 4 : SPLAT_RR;
+    static_assert(NH == 1 || NH == 2, "entries per lane");
     constexpr int AW = (GV < SplatGroup<CC>::G && GV >= 4) ? 3 : GV;   // the adder's wave index
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -806,7 +813,7 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
                 const unsigned k0 = L.vstart[v], k1 = L.vend[v];
-                const unsigned nt = (k1 - k0 + 63u) / 64u;
+                const unsigned nt = (k1 - k0 + (unsigned)TE - 1u) / (unsigned)TE;
                 n_steps = nt > n_steps ? nt : n_steps;
                 if (i == pw && wave != AW) { my_k0 = k0; my_k1 = k1; }
             }
@@ -820,63 +827,77 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             // ---- producer of vertex `wave`: barriers 0 .. n_steps - 1 close its tiles, one more ends the item
             const bool has = my_k1 > my_k0;
             const unsigned kc0 = has ? my_k0 : 0u, kc1 = has ? my_k1 : 1u;   // clamp range of the loads (entry 0 exists)
-            const unsigned n_tiles = has ? (my_k1 - my_k0 + 63u) / 64u : 0u;
-            float x[SPLAT_RR][CC];
-            float w[SPLAT_RE], nrm[SPLAT_RE];
-            unsigned pix[SPLAT_RE];
+            const unsigned n_tiles = has ? (my_k1 - my_k0 + (unsigned)TE - 1u) / (unsigned)TE : 0u;
+            float x[RR_][NH][CC];
+            float w[RE_][NH], nrm[RE_][NH];
+            unsigned pix[RE_][NH];
 #pragma unroll
-            for (int r = 0; r < SPLAT_RE; r++) { w[r] = 0.f; nrm[r] = 1.f; pix[r] = 0u; }
+            for (int r = 0; r < RE_; r++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) { w[r][h] = 0.f; nrm[r][h] = 1.f; pix[r][h] = 0u; }
             // loads are unconditional (indices clamped into the list): no divergent branch, counted waits
             auto load_entries = [&](unsigned tile, int slot) {
-                unsigned k = kc0 + tile * 64u + lane;
-                k = k < kc1 ? k : kc1 - 1u;
-                const uint2 pw = L.csr_pw[k];
-                w[slot] = __uint_as_float(pw.y);
-                pix[slot] = pw.x;
-                if (MODE == 1) nrm[slot] = L.csr_nrm[k];
+#pragma unroll
+                for (int h = 0; h < NH; h++) {
+                    unsigned k = kc0 + tile * (unsigned)TE + (unsigned)lane + 64u * h;
+                    k = k < kc1 ? k : kc1 - 1u;
+                    const uint2 pw = L.csr_pw[k];
+                    w[slot][h] = __uint_as_float(pw.y);
+                    pix[slot][h] = pw.x;
+                    if (MODE == 1) nrm[slot][h] = L.csr_nrm[k];
+                }
             };
             auto gather_rows = [&](int eslot, int rslot) {
                 if (MODE == 2) return;
-                // one frame-contiguous [point][C] matrix (the single-layer case): no division by N
-                const size_t row = contig ? (size_t)pix[eslot] * (unsigned)C + (unsigned)c0 : src.index(pix[eslot], c0, C, L.N);
-                if (FULL) {
-                    load_row<CC>(src.base + row, x[rslot]);
-                } else {
 #pragma unroll
-                    for (int c = 0; c < CC; c++) x[rslot][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+                for (int h = 0; h < NH; h++) {
+                    // one frame-contiguous [point][C] matrix (the single-layer case): no division by N
+                    const size_t row = contig ? (size_t)pix[eslot][h] * (unsigned)C + (unsigned)c0 : src.index(pix[eslot][h], c0, C, L.N);
+                    if (FULL) {
+                        load_row<CC>(src.base + row, x[rslot][h]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CC; c++) x[rslot][h][c] = src.base[row + (c < n_store ? c : n_store - 1)];
+                    }
                 }
             };
 #pragma unroll
-            for (int i = 0; i < SPLAT_RE - 1; i++) load_entries((unsigned)i, i);
+            for (int i = 0; i < RE_ - 1; i++) load_entries((unsigned)i, i);
 #pragma unroll
-            for (int i = 0; i < SPLAT_RR - 1; i++) gather_rows(i, i);
+            for (int i = 0; i < RR_ - 1; i++) gather_rows(i, i);
             // one tile: products -> LDS, refill the two rings, barrier.  `S` is a compile-time ring position
             // (the rings live in registers); a `false` return leaves the loop, so no stage is reachable
             // past a skipped one and the compiler keeps counted vmcnt waits.
             auto stage = [&](unsigned t, auto S) -> bool {
                 constexpr int s = decltype(S)::value;
                 if (t >= n_steps) return false;
-                const unsigned base = my_k0 + t * 64u;
-                const unsigned n_valid = t < n_tiles ? (my_k1 - base < 64u ? my_k1 - base : 64u) : 0u;
-                const float wl = (unsigned)lane < n_valid ? w[s] : 0.0f;
-                float (*pb)[68] = prod[t & 1u][pw];
+                const unsigned base = my_k0 + t * (unsigned)TE;
+                const unsigned n_valid = t < n_tiles ? (my_k1 - base < (unsigned)TE ? my_k1 - base : (unsigned)TE) : 0u;
+                float (*pb)[TE + 4] = prod[t & 1u][pw];
 #pragma unroll
-                for (int c = 0; c < CC; c++) {
-                    float xin = MODE == 2 ? 1.0f : x[s % SPLAT_RR][c];
-                    if (MODE == 1) xin = xin * nrm[s];
-                    const float pr = wl * xin;
-                    // +0 past the list: identity of the sum (FAST: wl is 0 there and the row is finite, so pr is +0 already)
-                    pb[c][lane] = (FAST || (unsigned)lane < n_valid) ? pr : 0.0f;
+                for (int h = 0; h < NH; h++) {
+                    const bool in = (unsigned)lane + 64u * h < n_valid;
+                    const float wl = in ? w[s][h] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CC; c++) {
+                        float xin = MODE == 2 ? 1.0f : x[s % RR_][h][c];
+                        if (MODE == 1) xin = xin * nrm[s][h];
+                        const float pr = wl * xin;
+                        // +0 past the list: identity of the sum (FAST: wl is 0 there and the row is finite, so pr is +0 already)
+                        pb[c][lane + 64 * h] = (FAST || in) ? pr : 0.0f;
+                    }
                 }
-                load_entries(t + SPLAT_RE - 1, (s + SPLAT_RE - 1) % SPLAT_RE);
-                gather_rows((s + SPLAT_RR - 1) % SPLAT_RE, (s + SPLAT_RR - 1) % SPLAT_RR);
+                load_entries(t + RE_ - 1, (s + RE_ - 1) % RE_);
+                gather_rows((s + RR_ - 1) % RE_, (s + RR_ - 1) % RR_);
                 __syncthreads();
                 return true;
             };
 #define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
-            for (unsigned t0 = 0;; t0 += SPLAT_RE) {
+            for (unsigned t0 = 0;; t0 += RE_) {
                 RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
-                RV_ST(8) RV_ST(9) RV_ST(10) RV_ST(11) RV_ST(12) RV_ST(13) RV_ST(14) RV_ST(15)
+                if constexpr (RE_ == 16) {
+                    RV_ST(8) RV_ST(9) RV_ST(10) RV_ST(11) RV_ST(12) RV_ST(13) RV_ST(14) RV_ST(15)
+                }
             }
 #undef RV_ST
             __syncthreads();
@@ -890,11 +911,11 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             __syncthreads();
             for (unsigned t = 0; t < n_steps; t++) {
                 const float* pr = prod[t & 1u][gi][c];
-                float4 q[16];
+                float4 q[16 * NH];
 #pragma unroll
-                for (int i = 0; i < 16; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
+                for (int i = 0; i < 16 * NH; i++) q[i] = reinterpret_cast<const float4*>(pr)[i];
 #pragma unroll
-                for (int i = 0; i < 16; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
+                for (int i = 0; i < 16 * NH; i++) { acc += q[i].x; acc += q[i].y; acc += q[i].z; acc += q[i].w; }
                 __syncthreads();
             }
             if (mine) values[(size_t)cv * C + c0 + c] = acc;
@@ -902,15 +923,15 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
     }
 }
 
-template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
+template <int MODE, int CC, bool FULL, int GV = SplatGroup<CC>::G, bool FAST = false, int NH = 1>   // FULL: all CC classes exist (n_store == CC): rows are fetched with wide loads
 __global__ void __launch_bounds__((GV + 1) * 64)
 splat_group_kernel(LatticeDev L, ValueView src, int C, int c0, int n_store, float* __restrict__ values) {
-    __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][68];  // 16-B aligned rows, 4-bank skew
+    __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][64 * NH + 4];  // 16-B aligned rows, 4-bank skew
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
-    splat_group_item<MODE, CC, FULL, GV, FAST>(L, src, C, c0, n_store, values, blockIdx.x, prod);
+    splat_group_item<MODE, CC, FULL, GV, FAST, NH>(L, src, C, c0, n_store, values, blockIdx.x, prod);
 }
 
-template <int MODE, int CC, int GV, bool FAST>
+template <int MODE, int CC, int GV, bool FAST, int NH = 1>
 static void splat_group_launch_g(const LatticeDev& L, const ValueView& src, int C, int c0, int n, float* values, hipStream_t s) {
     constexpr int G = GV;
     // items per XCD group: (frames of the group) x (groups of G vertices a frame can have at most)
@@ -918,7 +939,7 @@ static void splat_group_launch_g(const LatticeDev& L, const ValueView& src, int 
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned per_group = nfg * (unsigned)((max_mf + G - 1) / G);
     const dim3 grid(per_group * (unsigned)L.n_groups), block((G + 1) * 64);
-    if (n == CC) splat_group_kernel<MODE, CC, true, GV, FAST><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
+    if (n == CC) splat_group_kernel<MODE, CC, true, GV, FAST, NH><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
     else splat_group_kernel<MODE, CC, false, GV, false><<<grid, block, 0, s>>>(L, src, C, c0, n, values);
     RV_LAUNCHED("splat_group_kernel");
 }
@@ -966,11 +987,12 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         // the mean-field loop's own input (Q * norm written by the previous update): the fast producer, and the
         // block shape chosen for the chunk
         const int gv = splat_gv_choice(L);
+        // six vertices per block go with 128-entry tiles: both serve launches whose time is their longest chain
         if (C == 9) {
-            if (gv == 6) splat_group_launch_g<0, 9, 6, true>(L, src, C, 0, 9, values, s);
+            if (gv == 6) splat_group_launch_g<0, 9, 6, true, 2>(L, src, C, 0, 9, values, s);
             else splat_group_launch_g<0, 9, 7, true>(L, src, C, 0, 9, values, s);
         } else {
-            if (gv == 6) splat_group_launch_g<0, 8, 6, true>(L, src, C, 0, 8, values, s);
+            if (gv == 6) splat_group_launch_g<0, 8, 6, true, 2>(L, src, C, 0, 8, values, s);
             else splat_group_launch_g<0, 8, 8, true>(L, src, C, 0, 8, values, s);
         }
         return;
