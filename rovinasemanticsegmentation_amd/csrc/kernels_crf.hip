@@ -510,6 +510,78 @@ csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     }
 }
 
+// Count pass, four entries per lane.  The generic pass above walks a wave-block 64 entries at a time with two DEPENDENT
+// loads per step (slot, then slot -> vertex id): PMC showed its waves waiting 91 % of their cycles.  Counting needs no
+// order, so a lane takes four consecutive entries at once -- one 16-byte load, four id gathers in flight together, one
+// 16-byte store of the remapped ids -- and a wave-block is done in 7 steps instead of 28.
+__global__ void __launch_bounds__(256)
+csr_count_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
+    extern __shared__ unsigned cs_cnt[];   // [4 waves][mcap]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long gwb = (long long)blockIdx.x * 4 + wave;
+    const int frame = (int)(gwb / wbpf);
+    if (frame >= L.n_frames) return;       // whole wave; no block-wide barrier below
+    const int wb = (int)(gwb - (long long)frame * wbpf);
+    // (clamps only matter after a flagged hash overflow; they keep every access in bounds)
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    unsigned* my = cs_cnt + (size_t)wave * mcap;
+    unsigned* row = bh + (size_t)wbpf * f0 + (size_t)wb * Mf;
+    for (int lv = lane; lv < Mf; lv += 64) my[lv] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int dp1 = L.d + 1;
+    const long long p0 = (long long)wb * CS_PIX;
+    const long long p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const long long ebeg = ((long long)frame * L.N + p0) * dp1, eend = ((long long)frame * L.N + p1) * dp1;
+    auto fetch = [&](long long e, int (&sl)[4]) {   // slots of entries e .. e + 3 (clamped into the wave-block)
+        if (e + 4 <= eend) {
+            load_row<4>(L.offsets + e, sl);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sl[k] = e + k < eend ? L.offsets[e + k] : 0;
+        }
+    };
+    int sl_n[4];
+    fetch(ebeg + 4 * lane < eend ? ebeg + 4 * lane : ebeg, sl_n);
+    for (long long base = ebeg; base < eend; base += 256) {
+        const long long e = base + 4 * lane;
+        int sl[4], id[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) sl[k] = sl_n[k];
+        const bool any = e < eend;
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) id[k] = L.slot_to_id[sl[k]];   // four gathers in flight
+        }
+        const long long en = e + 256;
+        fetch(en < eend ? en : ebeg, sl_n);                             // the next step's slots travel meanwhile
+        if (!any) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // ids beyond the per-vertex arrays only occur after a (flagged) hash overflow: clamp so that every later
+            // kernel stays in bounds; the host discards the result
+            id[k] = id[k] < L.m_bound ? id[k] : L.m_bound - 1;
+        }
+        if (e + 4 <= eend) {
+            store_row<4>(L.offsets + e, id);                            // slot -> vertex id, in place
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (e + k < eend) L.offsets[e + k] = id[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (e + k >= eend) continue;
+            int lv = id[k] - f0;
+            lv = lv < Mf ? lv : Mf - 1;   // overflow case (flagged elsewhere): stay in bounds
+            lv = lv < 0 ? 0 : lv;
+            if (Mf > 0) atomicAdd(&my[lv], 1u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int lv = lane; lv < Mf; lv += 64) row[lv] = my[lv];
+}
+
 // Scatter pass with one lane per POINT (the generic pass above has one lane per entry and ranks ~10
 // distinct vertices per 64 entries; PMC: 438 vector instructions per 64 entries).  A chunk is 64
 // consecutive points x DP1 entries.  For every distinct vertex k of the chunk the lanes that hold k
@@ -662,7 +734,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         const long long waves = (long long)wbpf * L.n_frames;
         const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
-        csr_pass_kernel<false><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        csr_count_kernel<<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
         if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
