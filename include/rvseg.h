@@ -346,6 +346,9 @@ typedef struct rvseg_schedule {
     int32_t overlap_layers;      /* 1 (default): the label layers' mean fields on two streams                     */
     int32_t build_priority_high; /* 0 (default): the build stream has the lowest priority                         */
     int32_t trace;               /* 1: per-block trace of the resident splat (debugging); 2: + synchronous stderr marks */
+    int32_t serial_chains;       /* 0 (default): the normaliser's ordered sums by exact wave scans (kernels_crf.hip:
+                                    ordered_tile_sum); 1: one dependent addition per entry, like the reference loop.
+                                    Results are bit-identical; 1 exists for tests and timing                        */
 } rvseg_schedule;
 void rvseg_schedule_default(rvseg_schedule *s);
 /* Applies to every later call on ctx (buffers of a schedule are allocated on first use). */

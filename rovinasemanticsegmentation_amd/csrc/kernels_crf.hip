@@ -114,11 +114,11 @@ __device__ __forceinline__ int hash_lookup(const int* state, const unsigned long
 // ---------------------------------------------------------------------------------------------
 constexpr int LP_SET = 512;        // block-local vertex set (LP_CHUNKS x 256 points x (d+1) keys, few distinct)
 constexpr int LP_MAX_PROBE = 24;
-constexpr int LP_CHUNKS = 8;       // consecutive 256-point chunks per block: the set (and its global slots) carries over
+constexpr int LP_CHUNKS = 8;       // consecutive 256-point chunks per block (at most): the set (and its global slots) carries over
 
 template <int D>
 __global__ void __launch_bounds__(256)
-lattice_points_kernel(LatticeDev L, FeatureSource fs) {
+lattice_points_kernel(LatticeDev L, FeatureSource fs, int n_chunks) {
     // block-local vertex set: tag (EMPTY / LOCKED / FILLED), key, global slot; `lnew` lists the set
     // entries in creation order, so each chunk resolves only the entries it added
     __shared__ int ltag[LP_SET];
@@ -133,8 +133,8 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
     unsigned resolved = 0;   // set entries [0, resolved) of lnew already have their global slot
     const long long per_frame = L.Npad;
 
-  for (int chunk = 0; chunk < LP_CHUNKS; chunk++) {
-    const long long gid0 = ((long long)blockIdx.x * LP_CHUNKS + chunk) * 256 + threadIdx.x;
+  for (int chunk = 0; chunk < n_chunks; chunk++) {
+    const long long gid0 = ((long long)blockIdx.x * n_chunks + chunk) * 256 + threadIdx.x;
     const bool active = gid0 < per_frame * L.n_frames;   // all threads stay for the barriers
     const long long gid = active ? gid0 : 0;
     const int frame = (int)(gid / per_frame);
@@ -311,16 +311,20 @@ lattice_points_kernel(LatticeDev L, FeatureSource fs) {
 
 void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s) {
     const long long total = (long long)L.Npad * L.n_frames;
-    const long long per_block = 256ll * LP_CHUNKS;
+    // chunks per block: as many as leave >= 1024 blocks (a single frame or a cloud is a latency case: 150 blocks of
+    // 8 chunks kept three quarters of the chip idle for 106 us)
+    int n_chunks = LP_CHUNKS;
+    while (n_chunks > 1 && (total + 255) / 256 / n_chunks < 1024) n_chunks >>= 1;
+    const long long per_block = 256ll * n_chunks;
     const dim3 grid((unsigned)((total + per_block - 1) / per_block)), block(256);
     switch (L.d) {
-        case 1: lattice_points_kernel<1><<<grid, block, 0, s>>>(L, fs); break;
-        case 2: lattice_points_kernel<2><<<grid, block, 0, s>>>(L, fs); break;
-        case 3: lattice_points_kernel<3><<<grid, block, 0, s>>>(L, fs); break;
-        case 4: lattice_points_kernel<4><<<grid, block, 0, s>>>(L, fs); break;
-        case 5: lattice_points_kernel<5><<<grid, block, 0, s>>>(L, fs); break;
-        case 6: lattice_points_kernel<6><<<grid, block, 0, s>>>(L, fs); break;
-        case 7: lattice_points_kernel<7><<<grid, block, 0, s>>>(L, fs); break;
+        case 1: lattice_points_kernel<1><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 2: lattice_points_kernel<2><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 3: lattice_points_kernel<3><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 4: lattice_points_kernel<4><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 5: lattice_points_kernel<5><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 6: lattice_points_kernel<6><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
+        case 7: lattice_points_kernel<7><<<grid, block, 0, s>>>(L, fs, n_chunks); break;
         default: break;
     }
     RV_LAUNCHED("lattice_points_kernel");
@@ -656,65 +660,103 @@ csr_scatter_kernel(LatticeDev L, const unsigned* __restrict__ bh, int wbpf, int 
     }
 }
 
-// per frame: bh[wb][lv] (counts) -> absolute base of (wave-block, vertex) in the csr arrays;
-// vstart / vend per vertex.  1024 threads = 16 wave-block segments x 64 vertices.
+// per frame: bh[wb][lv] (counts) -> absolute base of (wave-block, vertex) in the csr arrays; vstart / vend per vertex.
+// Two launches over (frame, group of 64 vertices) blocks of 1024 threads = 16 wave-block segments x 64 vertices: the
+// first adds up the columns (per segment and whole), the second turns them into running bases.  The only thing a group
+// needs from the others is the number of entries of the vertices before it, which it adds up itself from the column
+// totals -- so the groups of a frame run side by side.  (Until round 3 one block per frame walked its groups one after
+// the other: 139 us for a single 640x480 frame, 461 us for a 1.1 M-point cloud, on the critical path of both.)
+constexpr int CS_SEGS = 16;
+__device__ __forceinline__ size_t csr_aux_offset(const LatticeDev& L, int wbpf) { return (size_t)wbpf * ((size_t)L.m_bound + 64); }
+
 __global__ void __launch_bounds__(1024)
-csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
-    __shared__ unsigned sseg[16][64];
-    __shared__ unsigned vbase[64];
-    __shared__ unsigned carry;
-    const int frame = blockIdx.x;
+csr_total_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap, int n_groups) {
+    __shared__ unsigned sseg[CS_SEGS][64];
+    const int frame = blockIdx.x / n_groups, grp = blockIdx.x - frame * n_groups;
     const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
     const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
     const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const int lv0 = grp * 64;
+    if (lv0 >= Mf) return;                   // whole block
     const int lvl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int sw = (wbpf + 15) / 16;
+    const int sw = (wbpf + CS_SEGS - 1) / CS_SEGS;
     const int w0 = seg * sw, w1 = (w0 + sw < wbpf) ? w0 + sw : wbpf;
-    unsigned* fb = bh + (size_t)wbpf * f0;   // dense [wave-block][vertex] matrix, row stride Mf
-    const unsigned frame_base = (unsigned)((long long)frame * L.N * (L.d + 1));
-    if (threadIdx.x == 0) carry = 0;
+    const unsigned* fb = bh + (size_t)wbpf * f0;   // dense [wave-block][vertex] matrix, row stride Mf
+    unsigned* vtot = bh + csr_aux_offset(L, wbpf);
+    unsigned* segsum = vtot + L.m_bound;
+    const int lv = lv0 + lvl;
+    const bool ok = lv < Mf;
+    unsigned sum = 0;
+    if (ok) for (int w = w0; w < w1; w++) sum += fb[(size_t)w * Mf + lv];
+    sseg[seg][lvl] = sum;
+    if (ok) segsum[(size_t)(f0 + lv) * CS_SEGS + seg] = sum;
     __syncthreads();
-    for (int lv0 = 0; lv0 < Mf; lv0 += 64) {
-        const int lv = lv0 + lvl;
-        const bool ok = lv < Mf;
-        unsigned sum = 0;
-        if (ok) for (int w = w0; w < w1; w++) sum += fb[(size_t)w * Mf + lv];
-        sseg[seg][lvl] = sum;
-        __syncthreads();
-        unsigned pre = 0, total = 0;
-        for (int q = 0; q < 16; q++) { const unsigned t = sseg[q][lvl]; if (q < seg) pre += t; total += t; }
-        if (seg == 0) {
-            // exclusive scan of the 64 column totals (one wave)
-            unsigned incl = total;
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned t = __shfl_up(incl, off, 64);
-                if (lvl >= off) incl += t;
-            }
-            const unsigned c0 = carry;
-            vbase[lvl] = c0 + incl - total;
-            if (ok) {
-                L.vstart[f0 + lv] = frame_base + c0 + incl - total;
-                L.vend[f0 + lv] = frame_base + c0 + incl;
-            }
-            if (lvl == 63) carry = c0 + incl;
+    if (seg == 0 && ok) {
+        unsigned total = 0;
+#pragma unroll
+        for (int q = 0; q < CS_SEGS; q++) total += sseg[q][lvl];
+        vtot[f0 + lv] = total;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap, int n_groups) {
+    __shared__ unsigned red[16];
+    __shared__ unsigned vbase[64];
+    const int frame = blockIdx.x / n_groups, grp = blockIdx.x - frame * n_groups;
+    const int f0 = L.fstart[frame] < L.m_bound ? L.fstart[frame] : L.m_bound;
+    const int f1 = L.fstart[frame + 1] < L.m_bound ? L.fstart[frame + 1] : L.m_bound;
+    const int Mf = f1 - f0 < mcap ? f1 - f0 : mcap;
+    const int lv0 = grp * 64;
+    if (lv0 >= Mf) return;                   // whole block
+    const int lvl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int sw = (wbpf + CS_SEGS - 1) / CS_SEGS;
+    const int w0 = seg * sw, w1 = (w0 + sw < wbpf) ? w0 + sw : wbpf;
+    unsigned* fb = bh + (size_t)wbpf * f0;
+    const unsigned* vtot = bh + csr_aux_offset(L, wbpf);
+    const unsigned* segsum = vtot + L.m_bound;
+    const unsigned frame_base = (unsigned)((long long)frame * L.N * (L.d + 1));
+    // entries of the frame's vertices before this group
+    unsigned part = 0;
+    for (int v = threadIdx.x; v < lv0; v += 1024) part += vtot[f0 + v];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lvl == 0) red[seg] = part;
+    __syncthreads();
+    unsigned carry = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) carry += red[q];
+    const int lv = lv0 + lvl;
+    const bool ok = lv < Mf;
+    if (seg == 0) {
+        const unsigned total = ok ? vtot[f0 + lv] : 0u;
+        unsigned incl = total;                // inclusive scan of the 64 column totals (one wave)
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lvl >= off) incl += t;
         }
-        __syncthreads();
+        vbase[lvl] = carry + incl - total;
         if (ok) {
-            unsigned run = frame_base + vbase[lvl] + pre;
-            for (int w = w0; w < w1; w++) {
-                const unsigned t = fb[(size_t)w * Mf + lv];
-                fb[(size_t)w * Mf + lv] = run;
-                run += t;
-            }
+            L.vstart[f0 + lv] = frame_base + carry + incl - total;
+            L.vend[f0 + lv] = frame_base + carry + incl;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (ok) {
+        unsigned run = frame_base + vbase[lvl];
+        for (int q = 0; q < seg; q++) run += segsum[(size_t)(f0 + lv) * CS_SEGS + q];
+        for (int w = w0; w < w1; w++) {
+            const unsigned t = fb[(size_t)w * Mf + lv];
+            fb[(size_t)w * Mf + lv] = run;
+            run += t;
+        }
     }
 }
 
 bool csr_fast_path(const LatticeDev& L) { return ((L.cap_f_mask + 1) / 2) <= (unsigned)CS_MCAP; }
 size_t csr_fast_bytes(const LatticeDev& L) {
     const size_t wbpf = ((size_t)L.N + CS_PIX - 1) / CS_PIX;
-    return wbpf * ((size_t)L.m_bound + 64) * sizeof(unsigned);
+    // the [wave-block][vertex] matrices of all frames, then per vertex its column total and CS_SEGS segment sums
+    return (wbpf * ((size_t)L.m_bound + 64) + (size_t)L.m_bound * (1 + CS_SEGS)) * sizeof(unsigned);
 }
 
 void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
@@ -735,7 +777,9 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
         csr_count_kernel<<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        csr_scan_kernel<<<dim3((unsigned)L.n_frames), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap);
+        const int n_groups = (mcap + 63) / 64;
+        csr_total_kernel<<<dim3((unsigned)(L.n_frames * n_groups)), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap, n_groups);
+        csr_scan_kernel<<<dim3((unsigned)(L.n_frames * n_groups)), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap, n_groups);
         if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
         else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
@@ -1031,6 +1075,249 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
     else splat_group_launch<MODE, 16>(L, src, C, c0, n, values, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The normaliser's splat (C = 1: a vertex's value is the fp32 sum of its entries' barycentric weights, added in list
+// order from +0) without the serial chain.  The ordered sum only LOOKS sequential: while the running sum s stays in one
+// binade [2^E, 2^(E+1)) every partial sum is a multiple of u = 2^(E-23), and adding w >= 0 to it rounds s + w to the
+// nearest multiple of u -- in units of u: n + k  ->  n + rne(k), k = w / u, unless k lies exactly half-way between two
+// integers (then the direction depends on the parity of n).  So, as long as no addend of a tile is negative or such a
+// tie and the tile does not leave the binade,
+//       s_after = (n + sum_i rne(k_i)) * u ,
+// a sum of integers below 2^24 -- exact in fp32 in ANY order.  A wave adds a tile of 128 addends (two per lane) with
+// one addition per lane and six DPP steps instead of 128 dependent additions; a tile that breaks a condition (the first
+// one, ~17 binade crossings and a few dozen ties per long list: 4-5 % of the tiles of a bench frame's heaviest lists) is
+// added the reference's way, one addend after the other.  The result is bit-identical to the sequential sum by
+// construction and is tested against it (tests/test_gpu_crf.py: test_normaliser_ordered_sums_...).
+// The same idea does not pay for the C-class splats: there the serial adder already runs 54 chains in its 64 lanes.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {   // the DPP-selected lane's v, +0 where the pattern selects none
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+// sum over the wave, valid in lane 63 (inclusive row scans, then the row totals travel up)
+__device__ __forceinline__ float wave_total_lane63(float v) {
+    v += dpp_term<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_term<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_term<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_term<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_term<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_term<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_term_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+// sum over the wave, the same value in every lane
+__device__ __forceinline__ unsigned wave_total_u32(unsigned v) {
+    v += dpp_term_u<0x111, 0xf>(v);
+    v += dpp_term_u<0x112, 0xf>(v);
+    v += dpp_term_u<0x114, 0xf>(v);
+    v += dpp_term_u<0x118, 0xf>(v);
+    v += dpp_term_u<0x142, 0xa>(v);
+    v += dpp_term_u<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// s + (128 addends: lane l holds entries 2l and 2l + 1), rounded after every addition like the sequential loop
+__device__ __forceinline__ float ordered_tile_sum(float s, float wa, float wb) {
+    const unsigned sb = __float_as_uint(s);
+    const unsigned e = (sb >> 23) & 0xffu;                       // biased exponent of the running sum
+    const bool s_ok = (int)sb > 0 && e >= 24u && e <= 253u;     // positive, normal, scale factors representable
+    const float scale = __uint_as_float((277u - (s_ok ? e : 127u)) << 23);      // 2^(23 - E) = 1 / u
+    const float unscale = __uint_as_float(((s_ok ? e : 127u) - 23u) << 23);     // u
+    const float ka = wa * scale, kb = wb * scale;                 // exact (a power of two)
+    const float ra = __builtin_rintf(ka), rb = __builtin_rintf(kb);   // round half to even, like the addition itself
+    const bool bad_lane = !(wa >= 0.0f) || !(wb >= 0.0f) || !(ka < 16777216.0f) || !(kb < 16777216.0f) ||
+                          __builtin_fabsf(ka - ra) == 0.5f || __builtin_fabsf(kb - rb) == 0.5f;
+    // (sums of integers: exact while below 2^24, and not below 2^24 once the true sum is not -- rounding is monotone)
+    const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_total_lane63(ra + rb)), 63));
+    const float S = s * scale + total;
+    if (s_ok && !__builtin_amdgcn_ballot_w64(bad_lane) && S < 16777216.0f) return S * unscale;
+    // the reference's way: one addition per addend, in list order
+    const int ia = __float_as_int(wa), ib = __float_as_int(wb);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        s = s + __int_as_float(__builtin_amdgcn_readlane(ia, i));
+        s = s + __int_as_float(__builtin_amdgcn_readlane(ib, i));
+    }
+    return s;
+}
+
+// Two kernels share the vertices of a frame (`vorder`: longest list first).
+//  * Lists of NS_HEAVY entries and more -- the chains that set the time of a launch with few frames: one block per
+//    vertex; wave 0 sums, waves 1..3 bring the list's weights into LDS three batches ahead of it (a single wave cannot
+//    keep enough loads in flight for itself: it sums 128 entries in ~0.1 us, a load takes 1-3 us to come back, and a
+//    register ring deep enough for that defeated the compiler's wait counting -- every variant ended in s_waitcnt
+//    vmcnt(0) or (1) per tile and ran at the speed of the serial chain).  One barrier per batch of 2 048 entries.
+//  * The short lists, thousands of them: one wave per vertex straight from global memory; their loads' latency is
+//    hidden by the other waves.
+constexpr int NS_HEAVY = 8192;                 // entries from which a list gets a block of its own
+constexpr int NS_BATCH = 2048;                 // entries per batch
+constexpr int NS_RING = 4;                     // batches of floats in LDS (32 KB): one being summed, three on their way
+constexpr int NS_SEGS = NS_BATCH / 128;        // 128-entry segments of a batch: one ordered_tile_sum each
+constexpr int NS_PROD = 3;                     // producer waves
+constexpr int NS_PER = (NS_SEGS + NS_PROD - 1) / NS_PROD;
+
+struct NormItem { unsigned frame, r; int fs0; unsigned n_vert; bool ok; };
+// item -> (rank r, frame) as in splat_group_item: every frame's heaviest vertices are dispatched first
+__device__ __forceinline__ NormItem norm_item(const LatticeDev& L, unsigned item) {
+    NormItem it{0u, 0u, 0, 0u, false};
+    const unsigned g = item % (unsigned)L.n_groups, j = item / (unsigned)L.n_groups;
+    const unsigned nfg = ((unsigned)L.n_frames - g + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
+    if (nfg == 0) return it;
+    it.r = j / nfg;
+    it.frame = g + (j - it.r * nfg) * (unsigned)L.n_groups;
+    const int Mtot = L.counters[0] < L.m_bound ? L.counters[0] : L.m_bound;
+    it.fs0 = L.fstart[it.frame] < Mtot ? L.fstart[it.frame] : Mtot;
+    const int fs1 = L.fstart[it.frame + 1] < Mtot ? L.fstart[it.frame + 1] : Mtot;
+    it.n_vert = (unsigned)(fs1 - it.fs0);
+    it.ok = true;
+    return it;
+}
+
+__device__ __forceinline__ void norm_sum_heavy(const LatticeDev& L, float* __restrict__ values, unsigned item, float (*buf)[NS_BATCH]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const NormItem it = norm_item(L, item);
+    if (!it.ok || it.r >= it.n_vert) return;
+    const unsigned v = L.vorder[(unsigned)it.fs0 + it.r];
+    const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+    const unsigned len = k1 - k0;
+    if (len < (unsigned)NS_HEAVY) return;   // (whole block) a light block's
+    const unsigned n_batch = (len + NS_BATCH - 1u) / NS_BATCH;
+    const float* wgt = reinterpret_cast<const float*>(L.csr_pw) + 1;   // the weight of entry k is wgt[2 k]
+    // producer wave: its share of batch q -- issue (loads, all in flight together) and, an iteration or two later, commit
+    auto issue = [&](unsigned q, float (&x)[NS_PER][2]) {
+        const unsigned base = k0 + q * NS_BATCH + 2u * (unsigned)lane;
+#pragma unroll
+        for (int i = 0; i < NS_PER; i++) {
+            const unsigned e = base + 128u * (unsigned)((wave - 1) + NS_PROD * i);
+#pragma unroll
+            for (int h = 0; h < 2; h++) x[i][h] = wgt[2 * (size_t)__builtin_elementwise_min(e + h, k1 - 1u)];
+        }
+    };
+    auto commit = [&](unsigned q, const float (&x)[NS_PER][2]) {
+        const unsigned base = k0 + q * NS_BATCH + 2u * (unsigned)lane;
+#pragma unroll
+        for (int i = 0; i < NS_PER; i++) {
+            const int seg = (wave - 1) + NS_PROD * i;
+            const unsigned e = base + 128u * (unsigned)seg;
+            if (seg < NS_SEGS)   // +0 past the end of the list: the identity of the sum
+                *reinterpret_cast<float2*>(&buf[q % NS_RING][seg * 128 + 2 * lane]) =
+                    make_float2(e < k1 ? x[i][0] : 0.0f, e + 1u < k1 ? x[i][1] : 0.0f);
+        }
+    };
+    // batches q + 1 and q + 2 travel in registers (xa: odd, xb: even batch numbers) while batch q is summed
+    float xa[NS_PER][2], xb[NS_PER][2];
+    float s = 0.0f;
+    if (wave > 0) {
+        issue(0, xb); commit(0, xb);
+        issue(1, xa); issue(2, xb);
+    }
+    __syncthreads();
+    for (unsigned q = 0; q < n_batch; q += 2) {
+        // even iteration: batch q is summed, q + 1 (xa) is committed, q + 3 issued into xa
+        if (wave > 0) { commit(q + 1u, xa); issue(q + 3u, xa); }
+        else {
+            const unsigned here = len - q * NS_BATCH < (unsigned)NS_BATCH ? len - q * NS_BATCH : (unsigned)NS_BATCH;
+            const float2* pb = reinterpret_cast<const float2*>(buf[q % NS_RING]) + lane;
+            const unsigned n_seg = (here + 127u) >> 7;
+            float2 w = pb[0];
+            for (unsigned sg = 0; sg < n_seg; sg++) {   // the next tile's LDS read travels during this tile's sum
+                const float2 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
+                s = ordered_tile_sum(s, w.x, w.y);
+                w = wn;
+            }
+        }
+        __syncthreads();
+        if (q + 1u >= n_batch) break;
+        // odd iteration: batch q + 1 is summed, q + 2 (xb) is committed, q + 4 issued into xb
+        if (wave > 0) { commit(q + 2u, xb); issue(q + 4u, xb); }
+        else {
+            const unsigned q1 = q + 1u;
+            const unsigned here = len - q1 * NS_BATCH < (unsigned)NS_BATCH ? len - q1 * NS_BATCH : (unsigned)NS_BATCH;
+            const float2* pb = reinterpret_cast<const float2*>(buf[q1 % NS_RING]) + lane;
+            const unsigned n_seg = (here + 127u) >> 7;
+            float2 w = pb[0];
+            for (unsigned sg = 0; sg < n_seg; sg++) {   // the next tile's LDS read travels during this tile's sum
+                const float2 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
+                s = ordered_tile_sum(s, w.x, w.y);
+                w = wn;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && lane == 0) values[v] = s;
+}
+
+constexpr int NS_WAVES = NS_PROD + 1;   // vertices (waves) per light block
+
+__device__ __forceinline__ void norm_sum_light(const LatticeDev& L, float* __restrict__ values, unsigned item, bool heavy_elsewhere) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const NormItem it = norm_item(L, item);
+    if (!it.ok) return;
+    const unsigned idx = it.r * NS_WAVES + (unsigned)wave;
+    if (idx >= it.n_vert) return;   // whole wave; no block-wide barrier on this path
+    const unsigned v = L.vorder[(unsigned)it.fs0 + idx];
+    const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+    if (heavy_elsewhere && k1 - k0 >= (unsigned)NS_HEAVY) return;   // a heavy block's
+    float s = 0.0f;
+    const float* wgt = reinterpret_cast<const float*>(L.csr_pw) + 1;
+    for (unsigned kb = k0; kb < k1; kb += 512u) {   // four tiles of 128 per step
+        float x[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned e = kb + 128u * t + 2u * (unsigned)lane + h;
+                const float y = wgt[2 * (size_t)__builtin_elementwise_min(e, k1 - 1u)];
+                x[t][h] = e < k1 ? y : 0.0f;   // +0 past the end: the identity of the sum
+            }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (kb + 128u * t < k1) s = ordered_tile_sum(s, x[t][0], x[t][1]);
+    }
+    if (lane == 0) values[v] = s;
+}
+
+// blocks [0, n_heavy_items): one long list each; the rest: NS_WAVES short lists each.  ONE launch, so that the short
+// lists are summed beside the long ones
+__global__ void __launch_bounds__(NS_WAVES * 64)
+norm_sum_kernel(LatticeDev L, float* __restrict__ values, unsigned n_heavy_items) {
+    __shared__ __attribute__((aligned(16))) float buf[NS_RING][NS_BATCH];
+    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
+    if (blockIdx.x < n_heavy_items) norm_sum_heavy(L, values, blockIdx.x, buf);
+    else norm_sum_light(L, values, blockIdx.x - n_heavy_items, n_heavy_items != 0u);
+}
+// the same without the LDS ring (chunks of many frames: no heavy blocks -- see launch_norm_sum)
+__global__ void __launch_bounds__(NS_WAVES * 64)
+norm_sum_light_kernel(LatticeDev L, float* __restrict__ values) {
+    if (L.counters[1]) return;
+    norm_sum_light(L, values, blockIdx.x, false);
+}
+
+static void launch_norm_sum(const LatticeDev& L, float* values, hipStream_t s) {
+    const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
+    const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
+    const unsigned n_light = nfg * (unsigned)((max_mf + NS_WAVES - 1) / NS_WAVES) * (unsigned)L.n_groups;
+    // A block (and 32 KB of LDS) per long list pays where the launch waits for its longest chains: a frame or two, a
+    // cloud.  In a chunk of many frames the lists are summed beside the feature kernels, which need the LDS and the
+    // wave slots more (measured at 64 frames: step 11.85 -> 12.2 ms with heavy blocks), and no single chain matters.
+    if (L.n_frames <= 4) {
+        // a frame of N points has at most 7 N / NS_HEAVY lists that long
+        const unsigned long long max_heavy = std::min<unsigned long long>(max_mf, (unsigned long long)(L.d + 1) * L.N / NS_HEAVY + 1);
+        const unsigned n_heavy_items = nfg * (unsigned)max_heavy * (unsigned)L.n_groups;
+        norm_sum_kernel<<<dim3(n_heavy_items + n_light), dim3(NS_WAVES * 64), 0, s>>>(L, values, n_heavy_items);
+    } else {
+        norm_sum_light_kernel<<<dim3(n_light), dim3(NS_WAVES * 64), 0, s>>>(L, values);
+    }
+    RV_LAUNCHED("norm_sum_kernel");
+}
+
 // vertices per block of the list-major walk for C = 8, 9 (rvseg_schedule.group_vertices: 0 = by the chunk's shape)
 static int splat_gv_choice(const LatticeDev& L) {
     if (L.group_vertices == 6 || L.group_vertices == 7) return L.group_vertices;
@@ -1045,7 +1332,8 @@ static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
 void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, float* values, hipStream_t s, bool own_q,
                   const SplatResidentDev* resident, int slot) {
     if (mode == 2) {
-        splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
+        if (L.ordered_sum_scan) launch_norm_sum(L, values, s);
+        else splat_group_launch<2, 1>(L, src, 1, 0, 1, values, s);
         return;
     }
     const bool contig = src.frame_stride == (size_t)L.N * (size_t)C && src.layer_off == 0;
@@ -1102,7 +1390,6 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
     __shared__ unsigned chv[RES_MAX_VERTS];
     __shared__ unsigned short own[RES_MAXB][RES_MAX_OWNV];
     __shared__ unsigned nown[RES_MAXB], nheavy[RES_MAXB];
-    __shared__ unsigned part[RES_PLAN_THREADS / 64];
     __shared__ unsigned short lvo[RES_MAX_VERTS];   // the frame's vertices, longest list first (`vorder`, frame-local)
     __shared__ unsigned cur[RES_MAXB];
     __shared__ unsigned blk0[RES_MAXB + 1];
@@ -1139,9 +1426,6 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
         if (ch) atomicAdd(&chv[lv], ch);
     }
     __syncthreads();
-    // ---- the heavy vertices, exactly.  Wave w evaluates block w % B on the bands w / B, w / B + wpj, ... (64 at a time)
-    const int wpj = (RES_PLAN_THREADS / 64) / B;              // waves per block (B <= 16)
-    const int my_j = wave % B, my_part = wave / B;
     // heavy = at least 12 chunks; `vorder` is sorted by length, so they are (about) a prefix of it: its length is counted
     if (tid < heavy_cap && tid < Mf && chv[lvo[tid]] >= (12u >> (clog - 6))) atomicAdd(&choice, 1);
     __syncthreads();
@@ -1155,40 +1439,36 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
         hc[i] = (unsigned char)((k1 - k0 + cmask) >> clog);
     }
     __syncthreads();
-    for (int k = 0; k < n_heavy; k++) {
-        const unsigned char* cb = hc + (size_t)k * nb;
-        unsigned sum = 0;
-        if (my_part < wpj)
-            for (int b = my_part * 64 + lane; b < nb; b += wpj * 64) {
-                const unsigned pk = T[my_j * nb + b], c = cb[b];
-                const unsigned mx = (pk & 255u) > c ? (pk & 255u) : c, t7 = ((pk >> 8) + c + 6u) / 7u;
-                sum += mx > t7 ? mx : t7;
-            }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (lane == 0) part[wave] = sum;
-        __syncthreads();
-        if (tid == 0) {
+    // ---- the heavy vertices, exactly, by ONE wave (lane = band): the loop is a chain of up to 160 dependent decisions,
+    // and with the whole workgroup on it every decision cost three block-wide barriers and an LDS round trip through
+    // thread 0 (0.45 ms per launch, 88 % of the wave cycles waiting); a single wave needs no barrier at all, the tile
+    // counts of the B candidate blocks are B independent DPP reductions
+    if (wave == 0) {
+        for (int k = 0; k < n_heavy; k++) {
+            const unsigned char* cb = hc + (size_t)k * nb;
             int best = -1; unsigned best_t = 0, best_inc = 0;
             for (int j = 0; j < B; j++) {
+                unsigned sum = 0;
+                for (int b = lane; b < nb; b += 64) {
+                    const unsigned pk = T[j * nb + b], c = cb[b];
+                    const unsigned mx = (pk & 255u) > c ? (pk & 255u) : c, t7 = ((pk >> 8) + c + 6u) / 7u;
+                    sum += mx > t7 ? mx : t7;
+                }
+                const unsigned t = wave_total_u32(sum);
                 if (nown[j] >= (unsigned)RES_MAX_OWNV) continue;
-                unsigned t = 0;
-                for (int q = 0; q < wpj; q++) t += part[j + q * B];
                 const unsigned inc = t - cur[j];
                 if (best < 0 || t < best_t || (t == best_t && inc < best_inc)) { best = j; best_t = t; best_inc = inc; }
             }
-            choice = best;
-            if (best < 0) bad = 1;
-            else { cur[best] = best_t; own[best][nown[best]++] = lvo[k]; }
+            if (best < 0) { if (lane == 0) bad = 1; break; }
+            for (int b = lane; b < nb; b += 64) {
+                const unsigned pk = T[best * nb + b], c = cb[b];
+                T[best * nb + b] = (((pk >> 8) + c) << 8) | ((pk & 255u) > c ? (pk & 255u) : c);
+            }
+            if (lane == 0) { cur[best] = best_t; own[best][nown[best]] = lvo[k]; nown[best] = nown[best] + 1u; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // one wave: LDS in program order; keeps the compiler from caching T / cur / nown
         }
-        __syncthreads();
-        if (bad) break;
-        const int jc = choice;
-        for (int b = tid; b < nb; b += RES_PLAN_THREADS) {
-            const unsigned pk = T[jc * nb + b], c = cb[b];
-            T[jc * nb + b] = (((pk >> 8) + c) << 8) | ((pk & 255u) > c ? (pk & 255u) : c);
-        }
-        __syncthreads();
     }
+    __syncthreads();
     if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
     // ---- the rest: fewest tiles so far, a vertex priced at chunks / 7 (sevenths of a tile in `cur7`)
     if (tid == 0) {

@@ -112,13 +112,17 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
 // are available.  The float additions follow the raster order exactly, so the result equals the
 // sequential algorithm wherever it is below 10 (and is >= 10 wherever that is).
 // ---------------------------------------------------------------------------------------------
-constexpr int DM_TW = 64, DM_TH = 16, DM_APRON = 20;
-constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 104
+// Tile shape: 24 rows + apron = 64 table rows = one lane per row with no lane idle (16 rows, 56 lanes until round 3:
+// 1.05 -> 0.94 ms for 64 frames with holes), 80 columns (0.75 ms: 31 KB of LDS, still five waves per CU; 96 columns
+// 0.91 ms with four, 128 columns 1.1 ms with three).
+constexpr int DM_TW = 80, DM_TH = 24, DM_APRON = 20;
+constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 120
 // row pitch of the LDS table.  Lane l touches row l at column t - 2l, i.e. word (pitch - 2) * l + t: with pitch 104
 // lanes l and l + 16 of a 32-lane group met in one bank (PMC: 62 % of the LDS-active cycles were conflict cycles);
 // an odd multiplier spreads a group over all 32 banks
 constexpr int DM_PITCH = DM_CW + 1;
-constexpr int DM_CH = DM_TH + 2 * DM_APRON;  // 56
+constexpr int DM_CH = DM_TH + 2 * DM_APRON;  // 64
+static_assert(DM_CH <= 64, "one lane per table row");
 
 // value of the lane below in the wave (lane l takes lane l-1's); lane 0 takes `edge`
 __device__ __forceinline__ float wave_shr1(float v, float edge) {

@@ -21,6 +21,7 @@ struct LatticeBufs {
     SortBuffers sb{};
     long long n_entries = 0, n_points = 0;
     bool built = false;
+    bool cleared = false;       // the build's memsets are already enqueued (crf_frames_build_begin)
     bool has_csr_nrm = false;   // per-entry normaliser (multi-kernel inference only)
 };
 
@@ -136,7 +137,6 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.state, cap * 4);
     RV_RES(b.tkeys, cap * 16);
     RV_RES(b.slot_to_id, cap * 4);
-    RV_RES(b.counters, 16);
     RV_RES(b.fstart, ((size_t)n_frames + 1) * 4);
     RV_RES(b.vkeys, m_bound * 16);
     RV_RES(b.offsets, E * 4);
@@ -144,8 +144,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     RV_RES(b.nb1, m_bound * (d + 1) * 4);
     RV_RES(b.nb2, m_bound * (d + 1) * 4);
     RV_RES(b.csr_pw, E * 8);
-    RV_RES(b.vstart, m_bound * 4);
-    RV_RES(b.vend, m_bound * 4);
+    RV_RES(b.vstart, (2 * m_bound + 4) * 4);   // vstart | vend | counters: one allocation, zeroed by ONE memset per build
     RV_RES(b.vorder, m_bound * 4);
     RV_RES(b.norm, P * 4);
     const unsigned long long SE = std::max<unsigned long long>((unsigned long long)E, m_bound);  // also sorts the vertex order
@@ -169,12 +168,13 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     const float inv_std_dev = (float)(std::sqrt(2.0 / 3.0) * (d + 1));
     for (int i = 0; i < 8; i++) L.scale[i] = i < d ? (float)(1.0 / std::sqrt((double)((i + 2) * (i + 1))) * inv_std_dev) : 0.f;
     L.state = b.state.as<int>(); L.tkeys = b.tkeys.as<unsigned long long>(); L.slot_to_id = b.slot_to_id.as<int>();
-    L.counters = b.counters.as<int>(); L.fstart = b.fstart.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
+    L.fstart = b.fstart.as<int>(); L.vkeys = b.vkeys.as<unsigned long long>();
     L.offsets = b.offsets.as<int>(); L.bary = b.bary.as<float>();
     L.nb1 = b.nb1.as<int>(); L.nb2 = b.nb2.as<int>();
     L.csr_pw = b.csr_pw.as<uint2>(); L.csr_nrm = nullptr;
     b.has_csr_nrm = false;
-    L.vstart = b.vstart.as<unsigned>(); L.vend = b.vend.as<unsigned>(); L.vorder = b.vorder.as<unsigned>(); L.norm = b.norm.as<float>();
+    L.vstart = b.vstart.as<unsigned>(); L.vend = L.vstart + m_bound; L.counters = reinterpret_cast<int*>(L.vend + m_bound);
+    L.vorder = b.vorder.as<unsigned>(); L.norm = b.norm.as<float>();
     L.n_groups = n_frames >= 8 ? 8 : 1;
     b.sb.keys_in = b.keys_in.as<unsigned>(); b.sb.keys_out = b.keys_out.as<unsigned>();
     b.sb.vals_in = b.vals_in.as<unsigned>(); b.sb.vals_out = b.vals_out.as<unsigned>();
@@ -183,6 +183,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     b.sb.block_hist = nullptr;
     L.bh = nullptr; L.wbpf = 0;
     L.group_vertices = ctx->sched.group_vertices;
+    L.ordered_sum_scan = ctx->sched.serial_chains ? 0 : 1;
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
         b.sb.block_hist = b.block_hist.as<unsigned>();
@@ -191,6 +192,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     }
     b.n_entries = E; b.n_points = P;
     b.built = false;
+    b.cleared = false;
     // Resident band schedule of the mean-field splat: chunks of many frames, whose splat is
     // bound by the bytes the list-major walk re-reads.  All n_frames x B blocks have to be on the chip together.
     b.resident_on = false;
@@ -262,12 +264,18 @@ static rvseg_status second_stream(rvseg_ctx* ctx, CrfState* cs) {
 }
 
 // Permutohedral::init + the normaliser of DenseKernel::initLattice (pairwise.cpp:40-56)
-static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, const FeatureSource& fs, hipStream_t s) {
+static rvseg_status lattice_clear(rvseg_ctx* ctx, LatticeBufs& b, hipStream_t s) {
     const LatticeDev& L = b.dev;
     RV_HIP(ctx, hipMemsetAsync(L.state, 0xFF, (size_t)L.cap_total * 4, s));
-    RV_HIP(ctx, hipMemsetAsync(L.counters, 0, 16, s));
-    RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (size_t)L.m_bound * 4, s));
-    RV_HIP(ctx, hipMemsetAsync(L.vend, 0, (size_t)L.m_bound * 4, s));
+    RV_HIP(ctx, hipMemsetAsync(L.vstart, 0, (2 * (size_t)L.m_bound + 4) * 4, s));   // vstart, vend, counters
+    b.cleared = true;
+    return RVSEG_OK;
+}
+
+static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, const FeatureSource& fs, hipStream_t s) {
+    const LatticeDev& L = b.dev;
+    if (!b.cleared) { rvseg_status stc = lattice_clear(ctx, b, s); if (stc != RVSEG_OK) return stc; }
+    b.cleared = false;
     const bool trace = ctx->sched.trace >= 2;
     auto tr = [&](const char* what) {
         if (!trace) return;
@@ -456,6 +464,13 @@ static rvseg_status mean_field(rvseg_ctx* ctx, CrfState* cs, int n_kernels, cons
 // The label layers of one lattice are independent mean fields (the reference runs one DenseCRF per layer,
 // segmenter.cpp:639-644).  Their splats wait for their longest chains rather than for bandwidth whenever a chunk
 // has few frames (a cloud, a 1280x960 chunk), so odd layers run on a second stream beside the even ones.
+// li-th layer to enqueue: odd layers (second stream) first when the layers run on two streams
+static int layer_enqueue_order(int li, int n_layers, bool two_streams) {
+    if (!two_streams) return li;
+    const int n_odd = n_layers / 2;
+    return li < n_odd ? 2 * li + 1 : 2 * (li - n_odd);
+}
+
 static rvseg_status layer_stream_fork(rvseg_ctx* ctx, CrfState* cs, hipStream_t s, int n_layers, hipStream_t* s2) {
     *s2 = s;
     if (n_layers < 2 || !ctx->sched.overlap_layers) return RVSEG_OK;
@@ -513,12 +528,14 @@ rvseg_status crf_frames_status(rvseg_ctx* ctx, Pipeline* im, bool wait) {
     return RVSEG_OK;
 }
 
-rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s) {
+// First half of crf_frames_build: status of the previous build, buffers, and the memsets of the new one.  None of it
+// needs the frames' cloud, so the frame path enqueues it on the build stream BEFORE that stream waits for prep_kernel
+// (40 us of a single frame's 2 ms).  `s` must already be ordered behind the previous user of the lattice.
+rvseg_status crf_frames_build_begin(rvseg_ctx* ctx, Pipeline* im, int n, hipStream_t s) {
     CrfState* cs;
     rvseg_status st = crf_state(ctx, im, &cs);
     if (st != RVSEG_OK) return st;
     const FrameGeom& g = im->geom;
-    const rvseg_params& p = ctx->params;
     const int N = g.W * g.H;
     // status of the previous asynchronous build (an earlier chunk of this call, or an earlier call whose
     // status nobody polled): its outputs were invalid, so this call must not pass for a clean one
@@ -526,6 +543,18 @@ rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
     if (cs->lat.size() < 1) cs->lat.resize(1);
     LatticeBufs& lb = cs->lat[0];
     if ((st = lattice_prepare(ctx, lb, 6, N, n, false, cs->frame_vertices_seen)) != RVSEG_OK) return st;
+    return lattice_clear(ctx, lb, s);
+}
+
+rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s) {
+    CrfState* cs;
+    rvseg_status st = crf_state(ctx, im, &cs);
+    if (st != RVSEG_OK) return st;
+    const rvseg_params& p = ctx->params;
+    if (cs->lat.size() < 1 || !cs->lat[0].cleared) {
+        if ((st = crf_frames_build_begin(ctx, im, n, s)) != RVSEG_OK) return st;
+    }
+    LatticeBufs& lb = cs->lat[0];
     FeatureSource fs{};
     fs.mode = 1; fs.cloud = im->cloud.as<float4>(); fs.rgb = d_rgb;
     fs.xyz_kernel = p.dcrf_xyz_kernel; fs.rgb_kernel = p.dcrf_rgb_kernel;
@@ -560,7 +589,13 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
     hipStream_t s2;
     if ((st = csr_nrm_before_fork(ctx, cs, f.n_layers, f.class_counts, p.dcrf_iterations, s)) != RVSEG_OK) return st;
     if ((st = layer_stream_fork(ctx, cs, s, f.n_layers, &s2)) != RVSEG_OK) return st;
-    for (int l = 0; l < f.n_layers; l++) {
+    // With two streams the layers of the SECOND stream are enqueued first: enqueuing a layer's whole loop takes the host
+    // a few hundred microseconds, during which the other stream has nothing to run, and the reference's second layer
+    // is the one with more classes (8 and 9: the longer loop starts first)
+    for (int li = 0; li < f.n_layers; li++) {
+        const int l = layer_enqueue_order(li, f.n_layers, s2 != s);
+        prefix = 0;
+        for (int k = 0; k < l; k++) prefix += f.class_counts[k];
         const int C = f.class_counts[l];
         ValueView U{const_cast<float*>(d_post), frame_stride, (size_t)N * prefix};
         ValueView Q{marg, frame_stride, (size_t)N * prefix};
@@ -571,7 +606,6 @@ rvseg_status crf_frames_infer(rvseg_ctx* ctx, Pipeline* im, int n, const float* 
         if ((st = mean_field(ctx, cs, 1, &w, U, false, C, N, (long long)N * n, p.dcrf_iterations, Q, slot ? s2 : s, d_labels ? &lab : nullptr,
                              &done, slot, slot == 0 || s2 == s)) != RVSEG_OK) { (void)layer_stream_join(ctx, cs, s, s2); return st; }
         all_labelled = all_labelled && done;
-        prefix += C;
     }
     if ((st = layer_stream_join(ctx, cs, s, s2)) != RVSEG_OK) return st;
     if (d_labels && !all_labelled) {
@@ -624,8 +658,10 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
     hipStream_t s2;
     if ((st = csr_nrm_before_fork(ctx, cs, n_layers, class_counts, iterations, s)) != RVSEG_OK) return st;
     if ((st = layer_stream_fork(ctx, cs, s, n_layers, &s2)) != RVSEG_OK) return st;
-    size_t prefix = 0;
-    for (int l = 0; l < n_layers; l++) {
+    for (int li = 0; li < n_layers; li++) {
+        const int l = layer_enqueue_order(li, n_layers, s2 != s);
+        size_t prefix = 0;
+        for (int k = 0; k < l; k++) prefix += (size_t)class_counts[k];
         const int C = class_counts[l];
         const int slot = l & 1;
         hipStream_t sl = slot ? s2 : s;
@@ -641,7 +677,6 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
             if (slot == 0 || s2 == s) timer_mark(ctx, "labels", sl);
             launch_labels(q, (size_t)N, C, label_mode, unknown[l], d_labels + (size_t)l * N, sl);
         }
-        prefix += C;
     }
     if ((st = layer_stream_join(ctx, cs, s, s2)) != RVSEG_OK) return st;
     RV_LAUNCH_OK(ctx);

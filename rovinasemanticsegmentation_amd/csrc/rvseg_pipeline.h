@@ -46,7 +46,7 @@ struct Pipeline {
     // the lattice build depends only on the cloud and the colours, not on the forest: it runs on a
     // side stream beside feature extraction + forest evaluation (fork after prep, join before inference)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_entry = nullptr;   // ev_entry: everything before this chunk on the caller's stream
 };
 
 rvseg_status pipeline_init(rvseg_ctx* ctx);
@@ -70,6 +70,7 @@ rvseg_status crf_cloud_layers(rvseg_ctx* ctx, int N, int n_layers, const int* cl
 // per-frame, per-layer DenseCRF on the frames of one chunk: unary = -(posteriors), features from
 // the back-projected cloud and the colours
 // part 1 (lattice + normaliser; needs the cloud only) and part 2 (mean field per layer + labels)
+rvseg_status crf_frames_build_begin(rvseg_ctx* ctx, Pipeline* im, int n, hipStream_t s);
 rvseg_status crf_frames_build(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t* d_rgb, hipStream_t s);
 // Status of the last enqueued frame build (consumes it): RVSEG_OK, RVSEG_NOT_READY (only without `wait`)
 // or RVSEG_ERR_CAPACITY after raising im->cap_boost.  RVSEG_OK when nothing is pending.

@@ -137,6 +137,7 @@ static void pipeline_free(Pipeline* im) {
     fusion_state_free(im);
     if (im->side) (void)hipStreamDestroy(im->side);
     if (im->ev_fork) (void)hipEventDestroy(im->ev_fork);
+    if (im->ev_entry) (void)hipEventDestroy(im->ev_entry);
     if (im->ev_join) (void)hipEventDestroy(im->ev_join);
 }
 
@@ -216,13 +217,11 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
         if ((st = dev_reserve(ctx, im->post, npix * f.sum_classes * 4 * n)) != RVSEG_OK) return st;
         post = im->post.as<float>();
     }
-    timer_mark(ctx, "prep", s);
-    launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
-                need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s,
-                use_lab2 ? im->lab2.as<uint2>() : nullptr);
-    bool forked = false;
-    if (p.use_dense_crf && ctx->sched.overlap_build) {
-        // fork: the lattice build runs on the side stream while this stream extracts features and walks the forest
+    const bool fork_build = p.use_dense_crf && ctx->sched.overlap_build;
+    if (fork_build) {
+        // the build stream first: table and list heads of the new lattice are cleared while prep_kernel runs.  The
+        // lattice's previous user (the last chunk's mean field, a cloud CRF on this context) ran on the caller's
+        // stream: ev_entry, recorded there before anything of this chunk, orders the memsets behind it.
         if (!im->side) {
             int prio_lo = 0, prio_hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -233,9 +232,21 @@ static rvseg_status run_chunk(rvseg_ctx* ctx, Pipeline* im, int n, const uint8_t
             RV_HIP(ctx, hipStreamCreateWithPriority(&im->side, hipStreamNonBlocking, ctx->sched.build_priority_high ? prio_hi : prio_lo));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_fork, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_join, hipEventDisableTiming));
+            RV_HIP(ctx, hipEventCreateWithFlags(&im->ev_entry, hipEventDisableTiming));
             RV_HIP(ctx, hipEventCreate(&ctx->timer.side0));
             RV_HIP(ctx, hipEventCreate(&ctx->timer.side1));
         }
+        RV_HIP(ctx, hipEventRecord(im->ev_entry, s));
+        RV_HIP(ctx, hipStreamWaitEvent(im->side, im->ev_entry, 0));
+        if ((st = crf_frames_build_begin(ctx, im, n, im->side)) != RVSEG_OK) return st;
+    }
+    timer_mark(ctx, "prep", s);
+    launch_prep(g, ctx->lab, d_rgb, d_depth, d_calibA, p.feature_color_patch ? im->lab.as<uint32_t>() : nullptr,
+                need_cloud ? im->cloud.as<float4>() : nullptr, p.feature_normal ? im->change.as<uint8_t>() : nullptr, n, s,
+                use_lab2 ? im->lab2.as<uint2>() : nullptr);
+    bool forked = false;
+    if (fork_build) {
+        // fork: the lattice build runs on the side stream while this stream extracts features and walks the forest
         RV_HIP(ctx, hipEventRecord(im->ev_fork, s));
         RV_HIP(ctx, hipStreamWaitEvent(im->side, im->ev_fork, 0));
         RV_HIP(ctx, hipEventRecord(ctx->timer.side0, im->side));

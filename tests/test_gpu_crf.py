@@ -59,6 +59,39 @@ def test_lattice_filter_skewed_vertices(gpu_ctx_factory, oracle):
     assert np.array_equal(ctx.lattice_filter(V), lat.compute(V))
 
 
+def _chain_features(kind, N, d, rng):
+    if kind == "skewed":        # nearly all points in one simplex, random weights: binade crossings and ties at random
+        return (rng.random((N, d)) * 0.05).astype(np.float32)
+    if kind == "constant":      # one weight vector repeated N times: whether an addition ties is the same all along a binade
+        return np.tile((rng.random((1, d)) * 0.7).astype(np.float32), (N, 1))
+    if kind == "origin":        # points ON a lattice vertex: weights exactly 1 and 0
+        return np.zeros((N, d), np.float32)
+    F = (rng.random((N, d)) * 0.05).astype(np.float32)      # "mixed": runs of equal weights between random ones
+    F[::3] = F[0]
+    F[N // 2:N // 2 + N // 8] = 0.0
+    return F
+
+
+@pytest.mark.parametrize("kind", ["skewed", "constant", "origin", "mixed"])
+def test_normaliser_ordered_sums_by_wave_scans_equal_the_serial_chain(gpu_ctx_factory, oracle, kind):
+    """The normaliser's splat adds a vertex's barycentric weights in list order in fp32.  The default kernel does that
+    with exact wave scans inside a binade and falls back to one addition per entry where a tile crosses a binade, holds
+    a round-to-even tie or a negative weight (kernels_crf.hip: ordered_tile_sum); rvseg_schedule.serial_chains = 1 is
+    the plain dependent chain.  Both must give the oracle's marginals bit for bit on lists of 10^5 entries -- a single
+    wrong rounding of a normaliser shows in every marginal of its simplex."""
+    rng = np.random.default_rng(len(kind))
+    N, d, C = 150000, 6, 3
+    F = _chain_features(kind, N, d, rng)
+    U = (rng.random((N, C)) * 3).astype(np.float32)
+    lat = oracle.Lattice(F)
+    assert lat.M < 200
+    want = oracle.crf_inference(U, F, 10.0, 2)
+    for serial in (0, 1):
+        ctx = gpu_ctx_factory(schedule=dict(serial_chains=serial))
+        Q, _ = ctx.crf_infer(U, F, 10.0, 2)
+        assert np.array_equal(Q, want), (kind, serial, float(np.abs(Q - want).max()))
+
+
 def test_hash_overflow_falls_back_to_safe_capacity(gpu_ctx_factory, oracle):
     # 2^4 slots cannot hold the lattice: the host entry points rebuild with the safe capacity
     F = _features(3, 2000, 3, spread=40.0)
