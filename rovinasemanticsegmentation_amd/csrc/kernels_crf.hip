@@ -1084,11 +1084,12 @@ static void splat_group_pass(const LatticeDev& L, const ValueView& src, int C, i
 // integers (then the direction depends on the parity of n).  So, as long as no addend of a tile is negative or such a
 // tie and the tile does not leave the binade,
 //       s_after = (n + sum_i rne(k_i)) * u ,
-// a sum of integers below 2^24 -- exact in fp32 in ANY order.  A wave adds a tile of 128 addends (two per lane) with
-// one addition per lane and six DPP steps instead of 128 dependent additions; a tile that breaks a condition (the first
-// one, ~17 binade crossings and a few dozen ties per long list: 4-5 % of the tiles of a bench frame's heaviest lists) is
-// added the reference's way, one addend after the other.  The result is bit-identical to the sequential sum by
-// construction and is tested against it (tests/test_gpu_crf.py: test_normaliser_ordered_sums_...).
+// a sum of integers below 2^24 -- exact in fp32 in ANY order.  A wave adds a tile of 128 or 256 addends (two or four
+// per lane) with a few additions per lane and six DPP steps instead of that many dependent additions; a tile that breaks
+// a condition (the first one, ~17 binade crossings and a few dozen ties per long list: 4-5 % of the 64-entry tiles of a
+// bench frame's heaviest lists) is tried again in two halves, and a half that breaks one is added the reference's way,
+// one addend after the other.  The result is bit-identical to the sequential sum by construction and is tested
+// against it (tests/test_gpu_crf.py: test_normaliser_ordered_sums_...).
 // The same idea does not pay for the C-class splats: there the serial adder already runs 54 chains in its 64 lanes.
 // ---------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -1121,28 +1122,50 @@ __device__ __forceinline__ unsigned wave_total_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// s + (128 addends: lane l holds entries 2l and 2l + 1), rounded after every addition like the sequential loop
-__device__ __forceinline__ float ordered_tile_sum(float s, float wa, float wb) {
+// One attempt at the lanes `mine` (K addends per lane, lane l holding entries K l .. K l + K - 1 of the tile): true and
+// s advanced if the conditions above hold for them, false and s untouched otherwise.
+template <int K>
+__device__ __forceinline__ bool ordered_try(float& s, const float (&w)[K], bool mine) {
     const unsigned sb = __float_as_uint(s);
-    const unsigned e = (sb >> 23) & 0xffu;                       // biased exponent of the running sum
-    const bool s_ok = (int)sb > 0 && e >= 24u && e <= 253u;     // positive, normal, scale factors representable
+    const unsigned e = (sb >> 23) & 0xffu;                              // biased exponent of the running sum
+    const bool s_ok = ((int)sb > 0) & (e >= 24u) & (e <= 253u);        // positive, normal, scale factors representable
     const float scale = __uint_as_float((277u - (s_ok ? e : 127u)) << 23);      // 2^(23 - E) = 1 / u
     const float unscale = __uint_as_float(((s_ok ? e : 127u) - 23u) << 23);     // u
-    const float ka = wa * scale, kb = wb * scale;                 // exact (a power of two)
-    const float ra = __builtin_rintf(ka), rb = __builtin_rintf(kb);   // round half to even, like the addition itself
-    const bool bad_lane = !(wa >= 0.0f) || !(wb >= 0.0f) || !(ka < 16777216.0f) || !(kb < 16777216.0f) ||
-                          __builtin_fabsf(ka - ra) == 0.5f || __builtin_fabsf(kb - rb) == 0.5f;
-    // (sums of integers: exact while below 2^24, and not below 2^24 once the true sum is not -- rounding is monotone)
-    const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_total_lane63(ra + rb)), 63));
-    const float S = s * scale + total;
-    if (s_ok && !__builtin_amdgcn_ballot_w64(bad_lane) && S < 16777216.0f) return S * unscale;
-    // the reference's way: one addition per addend, in list order
-    const int ia = __float_as_int(wa), ib = __float_as_int(wb);
+    float rs = 0.0f;
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        s = s + __int_as_float(__builtin_amdgcn_readlane(ia, i));
-        s = s + __int_as_float(__builtin_amdgcn_readlane(ib, i));
+    for (int h = 0; h < K; h++) {
+        const float k = w[h] * scale;                 // exact (a power of two)
+        const float r = __builtin_rintf(k);           // round half to even, like the addition itself
+        bad |= !(w[h] >= 0.0f) | !(k < 16777216.0f) | (__builtin_fabsf(k - r) == 0.5f);
+        rs += r;
     }
+    rs = mine ? rs : 0.0f;
+    bad &= mine;
+    // (sums of integers: exact while below 2^24, and not below 2^24 once the true sum is not -- rounding is monotone)
+    const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_total_lane63(rs)), 63));
+    const float S = s * scale + total;
+    const bool ok = s_ok & (__builtin_amdgcn_ballot_w64(bad) == 0ull) & (S < 16777216.0f);
+    if (ok) s = S * unscale;
+    return ok;
+}
+// the reference's way for lanes [LO, HI): one addition per addend, in list order
+template <int K, int LO, int HI>
+__device__ __forceinline__ float ordered_serial(float s, const float (&w)[K]) {
+#pragma unroll
+    for (int i = LO; i < HI; i++)
+#pragma unroll
+        for (int h = 0; h < K; h++) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[h]), i));
+    return s;
+}
+// s + (a tile of 64 K addends), rounded after every addition like the sequential loop: the whole tile at once if it can
+// be, else its two halves, each at once or serially
+template <int K>
+__device__ __forceinline__ float ordered_tile_sum(float s, const float (&w)[K]) {
+    if (ordered_try<K>(s, w, true)) return s;
+    const bool low = (threadIdx.x & 63) < 32;
+    if (!ordered_try<K>(s, w, low)) s = ordered_serial<K, 0, 32>(s, w);
+    if (!ordered_try<K>(s, w, !low)) s = ordered_serial<K, 32, 64>(s, w);
     return s;
 }
 
@@ -1157,7 +1180,8 @@ __device__ __forceinline__ float ordered_tile_sum(float s, float wa, float wb) {
 constexpr int NS_HEAVY = 8192;                 // entries from which a list gets a block of its own
 constexpr int NS_BATCH = 2048;                 // entries per batch
 constexpr int NS_RING = 4;                     // batches of floats in LDS (32 KB): one being summed, three on their way
-constexpr int NS_SEGS = NS_BATCH / 128;        // 128-entry segments of a batch: one ordered_tile_sum each
+constexpr int NS_K = 4;                        // entries per lane and tile on the heavy path: tiles of 256
+constexpr int NS_SEGS = NS_BATCH / (64 * NS_K);   // tiles of a batch: one ordered_tile_sum each
 constexpr int NS_PROD = 3;                     // producer waves
 constexpr int NS_PER = (NS_SEGS + NS_PROD - 1) / NS_PROD;
 
@@ -1190,28 +1214,29 @@ __device__ __forceinline__ void norm_sum_heavy(const LatticeDev& L, float* __res
     const unsigned n_batch = (len + NS_BATCH - 1u) / NS_BATCH;
     const float* wgt = reinterpret_cast<const float*>(L.csr_pw) + 1;   // the weight of entry k is wgt[2 k]
     // producer wave: its share of batch q -- issue (loads, all in flight together) and, an iteration or two later, commit
-    auto issue = [&](unsigned q, float (&x)[NS_PER][2]) {
-        const unsigned base = k0 + q * NS_BATCH + 2u * (unsigned)lane;
+    auto issue = [&](unsigned q, float (&x)[NS_PER][NS_K]) {
+        const unsigned base = k0 + q * NS_BATCH + (unsigned)(NS_K * lane);
 #pragma unroll
         for (int i = 0; i < NS_PER; i++) {
-            const unsigned e = base + 128u * (unsigned)((wave - 1) + NS_PROD * i);
+            const unsigned e = base + (unsigned)(64 * NS_K) * (unsigned)((wave - 1) + NS_PROD * i);
 #pragma unroll
-            for (int h = 0; h < 2; h++) x[i][h] = wgt[2 * (size_t)__builtin_elementwise_min(e + h, k1 - 1u)];
+            for (int h = 0; h < NS_K; h++) x[i][h] = wgt[2 * (size_t)__builtin_elementwise_min(e + h, k1 - 1u)];
         }
     };
-    auto commit = [&](unsigned q, const float (&x)[NS_PER][2]) {
-        const unsigned base = k0 + q * NS_BATCH + 2u * (unsigned)lane;
+    auto commit = [&](unsigned q, const float (&x)[NS_PER][NS_K]) {
+        const unsigned base = k0 + q * NS_BATCH + (unsigned)(NS_K * lane);
 #pragma unroll
         for (int i = 0; i < NS_PER; i++) {
             const int seg = (wave - 1) + NS_PROD * i;
-            const unsigned e = base + 128u * (unsigned)seg;
+            const unsigned e = base + (unsigned)(64 * NS_K) * (unsigned)seg;
             if (seg < NS_SEGS)   // +0 past the end of the list: the identity of the sum
-                *reinterpret_cast<float2*>(&buf[q % NS_RING][seg * 128 + 2 * lane]) =
-                    make_float2(e < k1 ? x[i][0] : 0.0f, e + 1u < k1 ? x[i][1] : 0.0f);
+                *reinterpret_cast<float4*>(&buf[q % NS_RING][seg * 64 * NS_K + NS_K * lane]) =
+                    make_float4(e < k1 ? x[i][0] : 0.0f, e + 1u < k1 ? x[i][1] : 0.0f, e + 2u < k1 ? x[i][2] : 0.0f, e + 3u < k1 ? x[i][3] : 0.0f);
         }
     };
     // batches q + 1 and q + 2 travel in registers (xa: odd, xb: even batch numbers) while batch q is summed
-    float xa[NS_PER][2], xb[NS_PER][2];
+    static_assert(NS_K == 4, "the LDS tiles are float4 per lane");
+    float xa[NS_PER][NS_K], xb[NS_PER][NS_K];
     float s = 0.0f;
     if (wave > 0) {
         issue(0, xb); commit(0, xb);
@@ -1223,12 +1248,13 @@ __device__ __forceinline__ void norm_sum_heavy(const LatticeDev& L, float* __res
         if (wave > 0) { commit(q + 1u, xa); issue(q + 3u, xa); }
         else {
             const unsigned here = len - q * NS_BATCH < (unsigned)NS_BATCH ? len - q * NS_BATCH : (unsigned)NS_BATCH;
-            const float2* pb = reinterpret_cast<const float2*>(buf[q % NS_RING]) + lane;
-            const unsigned n_seg = (here + 127u) >> 7;
-            float2 w = pb[0];
+            const float4* pb = reinterpret_cast<const float4*>(buf[q % NS_RING]) + lane;
+            const unsigned n_seg = (here + (unsigned)(64 * NS_K - 1)) / (unsigned)(64 * NS_K);
+            float4 w = pb[0];
             for (unsigned sg = 0; sg < n_seg; sg++) {   // the next tile's LDS read travels during this tile's sum
-                const float2 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
-                s = ordered_tile_sum(s, w.x, w.y);
+                const float4 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
+                const float wk[NS_K] = {w.x, w.y, w.z, w.w};
+                s = ordered_tile_sum<NS_K>(s, wk);
                 w = wn;
             }
         }
@@ -1239,12 +1265,13 @@ __device__ __forceinline__ void norm_sum_heavy(const LatticeDev& L, float* __res
         else {
             const unsigned q1 = q + 1u;
             const unsigned here = len - q1 * NS_BATCH < (unsigned)NS_BATCH ? len - q1 * NS_BATCH : (unsigned)NS_BATCH;
-            const float2* pb = reinterpret_cast<const float2*>(buf[q1 % NS_RING]) + lane;
-            const unsigned n_seg = (here + 127u) >> 7;
-            float2 w = pb[0];
+            const float4* pb = reinterpret_cast<const float4*>(buf[q1 % NS_RING]) + lane;
+            const unsigned n_seg = (here + (unsigned)(64 * NS_K - 1)) / (unsigned)(64 * NS_K);
+            float4 w = pb[0];
             for (unsigned sg = 0; sg < n_seg; sg++) {   // the next tile's LDS read travels during this tile's sum
-                const float2 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
-                s = ordered_tile_sum(s, w.x, w.y);
+                const float4 wn = pb[64u * (sg + 1u < (unsigned)NS_SEGS ? sg + 1u : sg)];
+                const float wk[NS_K] = {w.x, w.y, w.z, w.w};
+                s = ordered_tile_sum<NS_K>(s, wk);
                 w = wn;
             }
         }
@@ -1279,7 +1306,7 @@ __device__ __forceinline__ void norm_sum_light(const LatticeDev& L, float* __res
             }
 #pragma unroll
         for (int t = 0; t < 4; t++)
-            if (kb + 128u * t < k1) s = ordered_tile_sum(s, x[t][0], x[t][1]);
+            if (kb + 128u * t < k1) s = ordered_tile_sum<2>(s, x[t]);
     }
     if (lane == 0) values[v] = s;
 }
