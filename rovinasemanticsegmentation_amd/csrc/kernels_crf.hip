@@ -929,6 +929,7 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
                 const unsigned k0 = L.vstart[v], k1 = L.vend[v];
+                if (L.heavy_from && k1 - k0 >= L.heavy_from) continue;   // a scan block's (splat_scan_item)
                 const unsigned nt = (k1 - k0 + (unsigned)TE - 1u) / (unsigned)TE;
                 n_steps = nt > n_steps ? nt : n_steps;
                 if (i == pw && wave != AW) { my_k0 = k0; my_k1 = k1; }
@@ -1021,8 +1022,9 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             // ---- adder: lane (i, c) owns the chain of vertex i, class c
             const int gi = lane < G * CC ? lane / CC : 0, c = lane < G * CC ? lane % CC : 0;
             const unsigned idx = r * G + gi;
-            const bool mine = lane < G * CC && idx < n_vert && c < n_store;
+            bool mine = lane < G * CC && idx < n_vert && c < n_store;
             const unsigned cv = mine ? L.vorder[gstart + idx] : 0u;
+            if (mine && L.heavy_from && L.vend[cv] - L.vstart[cv] >= L.heavy_from) mine = false;   // a scan block's
             float acc = 0.0f;
             __syncthreads();
             for (unsigned t = 0; t < n_steps; t++) {
@@ -1345,6 +1347,125 @@ static void launch_norm_sum(const LatticeDev& L, float* values, hipStream_t s) {
     RV_LAUNCHED("norm_sum_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scan blocks of the list-major walk: the long lists of launches that wait for their longest chains (a frame or two, a
+// cloud).  One vertex per block: wave 0 is the producer of splat_group_item (128-entry tiles of products into a
+// double-buffered LDS tile, register rings of entries and rows), waves 1 .. CC add one class each with
+// ordered_tile_sum -- a wave scan per tile where the serial adder spends 128 dependent additions per class.  Mode 0 on
+// the loop's own contiguous Q * norm only (the FAST producer: padding lanes have weight 0, the rows are finite).
+// The same launch carries the regular blocks for the shorter lists (LatticeDev::heavy_from tells them which to leave).
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned SPLAT_HEAVY = 16384;   // entries from which a list gets a scan block
+
+template <int CC>
+__device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const ValueView& src, float* __restrict__ values, unsigned item,
+                                                float (*prod)[CC][128 + 4]) {
+    constexpr int NH = 2, TE = 128, RE_ = 8, RR_ = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave > CC) return;
+    const NormItem it = norm_item(L, item);
+    if (!it.ok || it.r >= it.n_vert) return;
+    const unsigned v = L.vorder[(unsigned)it.fs0 + it.r];
+    const unsigned my_k0 = L.vstart[v], my_k1 = L.vend[v];
+    if (my_k1 - my_k0 < L.heavy_from) return;   // (whole block) a regular block's
+    const unsigned n_steps = (my_k1 - my_k0 + (unsigned)TE - 1u) / (unsigned)TE;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(1);
+        float x[RR_][NH][CC];
+        float w[RE_][NH];
+        unsigned pix[RE_][NH];
+#pragma unroll
+        for (int r = 0; r < RE_; r++)
+#pragma unroll
+            for (int h = 0; h < NH; h++) { w[r][h] = 0.f; pix[r][h] = 0u; }
+        // loads are unconditional (indices clamped into the list): no divergent branch, counted waits
+        auto load_entries = [&](unsigned tile, int slot) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                unsigned k = my_k0 + tile * (unsigned)TE + (unsigned)lane + 64u * h;
+                k = k < my_k1 ? k : my_k1 - 1u;
+                const uint2 pw = L.csr_pw[k];
+                w[slot][h] = __uint_as_float(pw.y);
+                pix[slot][h] = pw.x;
+            }
+        };
+        auto gather_rows = [&](int eslot, int rslot) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) load_row<CC>(src.base + (size_t)pix[eslot][h] * (unsigned)CC, x[rslot][h]);
+        };
+#pragma unroll
+        for (int i = 0; i < RE_ - 1; i++) load_entries((unsigned)i, i);
+#pragma unroll
+        for (int i = 0; i < RR_ - 1; i++) gather_rows(i, i);
+        auto stage = [&](unsigned t, auto S) -> bool {
+            constexpr int s = decltype(S)::value;
+            if (t >= n_steps) return false;
+            const unsigned base = my_k0 + t * (unsigned)TE;
+            const unsigned n_valid = my_k1 - base < (unsigned)TE ? my_k1 - base : (unsigned)TE;
+            float (*pb)[TE + 4] = prod[t & 1u];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const bool in = (unsigned)lane + 64u * h < n_valid;
+                const float wl = in ? w[s][h] : 0.0f;   // +0 past the list: the product is +0, the identity of the sum
+#pragma unroll
+                for (int c = 0; c < CC; c++) pb[c][lane + 64 * h] = wl * x[s % RR_][h][c];
+            }
+            load_entries(t + RE_ - 1, (s + RE_ - 1) % RE_);
+            gather_rows((s + RR_ - 1) % RE_, (s + RR_ - 1) % RR_);
+            __syncthreads();
+            return true;
+        };
+#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
+        for (unsigned t0 = 0;; t0 += RE_) {
+            RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
+        }
+#undef RV_ST
+        __syncthreads();
+    } else {
+        // ---- adder of class c: entries 2 l and 2 l + 1 of a tile in lane l
+        __builtin_amdgcn_s_setprio(3);
+        const int c = wave - 1;
+        float acc = 0.0f;
+        __syncthreads();
+        for (unsigned t = 0; t < n_steps; t++) {
+            const float2 q = *reinterpret_cast<const float2*>(&prod[t & 1u][c][2 * lane]);
+            const float wk[2] = {q.x, q.y};
+            acc = ordered_tile_sum<2>(acc, wk);
+            __syncthreads();
+        }
+        if (lane == 0) values[(size_t)v * CC + c] = acc;
+    }
+}
+
+// blocks [0, n_scan_items): scan blocks; the rest: regular blocks of GV vertices (their waves beyond GV + 1 leave at once)
+template <int CC, int GV>
+__global__ void __launch_bounds__((CC + 1) * 64)
+splat_mixed_kernel(LatticeDev L, ValueView src, float* __restrict__ values, unsigned n_scan_items) {
+    static_assert(GV + 1 <= CC + 1, "block size");
+    __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][64 * 2 + 4];
+    if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
+    if (blockIdx.x < n_scan_items) {
+        splat_scan_item<CC>(L, src, values, blockIdx.x, reinterpret_cast<float (*)[CC][128 + 4]>(&prod[0][0][0][0]));
+    } else {
+        if ((int)(threadIdx.x >> 6) > GV) return;
+        splat_group_item<0, CC, true, GV, true, 2>(L, src, CC, 0, CC, values, blockIdx.x - n_scan_items, prod);
+    }
+}
+
+template <int CC, int GV>
+static void splat_mixed_launch(const LatticeDev& L0, const ValueView& src, float* values, hipStream_t s) {
+    LatticeDev L = L0;
+    L.heavy_from = SPLAT_HEAVY;
+    const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
+    const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
+    const unsigned long long max_heavy = std::min<unsigned long long>(max_mf, (unsigned long long)(L.d + 1) * L.N / SPLAT_HEAVY + 1);
+    const unsigned n_scan = nfg * (unsigned)max_heavy * (unsigned)L.n_groups;
+    const unsigned n_regular = nfg * (unsigned)((max_mf + GV - 1) / GV) * (unsigned)L.n_groups;
+    splat_mixed_kernel<CC, GV><<<dim3(n_scan + n_regular), dim3((CC + 1) * 64), 0, s>>>(L, src, values, n_scan);
+    RV_LAUNCHED("splat_mixed_kernel");
+}
+
 // vertices per block of the list-major walk for C = 8, 9 (rvseg_schedule.group_vertices: 0 = by the chunk's shape)
 static int splat_gv_choice(const LatticeDev& L) {
     if (L.group_vertices == 6 || L.group_vertices == 7) return L.group_vertices;
@@ -1375,6 +1496,12 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         // block shape chosen for the chunk
         const int gv = splat_gv_choice(L);
         // six vertices per block go with 128-entry tiles: both serve launches whose time is their longest chain
+        // a frame or two, a cloud: the launch waits for its longest chains -- those get scan blocks
+        if (gv == 6 && L.n_frames <= 4 && L.ordered_sum_scan) {
+            if (C == 9) splat_mixed_launch<9, 6>(L, src, values, s);
+            else splat_mixed_launch<8, 6>(L, src, values, s);
+            return;
+        }
         if (C == 9) {
             if (gv == 6) splat_group_launch_g<0, 9, 6, true, 2>(L, src, C, 0, 9, values, s);
             else splat_group_launch_g<0, 9, 7, true>(L, src, C, 0, 9, values, s);

@@ -36,6 +36,7 @@ struct LatticeDev {
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
     int group_vertices;          // list-major walk, C = 8 / 9: vertices per block (0 = by the chunk's shape, 6, 7)
     int ordered_sum_scan;        // normaliser: exact wave-scan sums (1) or the serial chain (0); same bits either way
+    unsigned heavy_from;         // list-major walk: lists of this many entries and more belong to scan blocks (0 = none)
     // counting-sort path: after the scan, bh[wave-block][vertex] is the position of the vertex's first entry at or
     // after that wave-block, i.e. the vertex-major lists can be cut at any multiple of CS_PIX points without
     // another sort (the resident band schedule does)

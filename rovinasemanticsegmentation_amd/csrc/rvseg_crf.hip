@@ -184,6 +184,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.bh = nullptr; L.wbpf = 0;
     L.group_vertices = ctx->sched.group_vertices;
     L.ordered_sum_scan = ctx->sched.serial_chains ? 0 : 1;
+    L.heavy_from = 0;
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
         b.sb.block_hist = b.block_hist.as<unsigned>();

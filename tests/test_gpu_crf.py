@@ -92,6 +92,25 @@ def test_normaliser_ordered_sums_by_wave_scans_equal_the_serial_chain(gpu_ctx_fa
         assert np.array_equal(Q, want), (kind, serial, float(np.abs(Q - want).max()))
 
 
+@pytest.mark.parametrize("C", [9, 8])
+@pytest.mark.parametrize("kind", ["skewed", "mixed"])
+def test_long_lists_summed_by_scan_blocks_equal_the_serial_adder(gpu_ctx_factory, oracle, C, kind):
+    """Launches of a few frames (here: one cloud) give every list of 16 384 entries and more a scan block: one wave per
+    class adds the tile's products with ordered_tile_sum instead of the serial adder's 128 dependent additions
+    (kernels_crf.hip: splat_scan_item).  Lists of 10^5 entries, 8 and 9 classes (the two block shapes), against the
+    oracle bit for bit, with rvseg_schedule.serial_chains = 1 (the serial adder everywhere) as the second witness."""
+    rng = np.random.default_rng(C * 7 + len(kind))
+    N, d = 120000, 6
+    F = _chain_features(kind, N, d, rng)
+    U = (rng.random((N, C)) * 4).astype(np.float32)
+    want = oracle.crf_inference(U, F, 10.0, 3)
+    for serial in (0, 1):
+        ctx = gpu_ctx_factory(schedule=dict(serial_chains=serial))
+        Q, mp = ctx.crf_infer(U, F, 10.0, 3)
+        assert np.array_equal(Q, want), (C, kind, serial, float(np.abs(Q - want).max()))
+        assert np.array_equal(mp, want.argmax(1).astype(np.int8))
+
+
 def test_hash_overflow_falls_back_to_safe_capacity(gpu_ctx_factory, oracle):
     # 2^4 slots cannot hold the lattice: the host entry points rebuild with the safe capacity
     F = _features(3, 2000, 3, spread=40.0)
