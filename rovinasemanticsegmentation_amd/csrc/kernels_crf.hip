@@ -1349,58 +1349,65 @@ static void launch_norm_sum(const LatticeDev& L, float* values, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Scan blocks of the list-major walk: the long lists of launches that wait for their longest chains (a frame or two, a
-// cloud).  One vertex per block: wave 0 is the producer of splat_group_item (128-entry tiles of products into a
-// double-buffered LDS tile, register rings of entries and rows), waves 1 .. CC add one class each with
-// ordered_tile_sum -- a wave scan per tile where the serial adder spends 128 dependent additions per class.  Mode 0 on
+// cloud).  One vertex per block: two producer waves like those of splat_group_item (128-entry tiles of products into a
+// double-buffered LDS tile, register rings of entries and rows; the tiles alternate between the two, so each has two
+// steps per tile and its row gathers a lead of six steps -- with one producer the 0.2 us steps outran its rings), and CC
+// waves that add one class each with ordered_tile_sum: a wave scan per tile where the serial adder spends 128
+// dependent additions per class.  Mode 0 on
 // the loop's own contiguous Q * norm only (the FAST producer: padding lanes have weight 0, the rows are finite).
 // The same launch carries the regular blocks for the shorter lists (LatticeDev::heavy_from tells them which to leave).
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned SPLAT_HEAVY = 16384;   // entries from which a list gets a scan block
 
-template <int CC>
-__device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const ValueView& src, float* __restrict__ values, unsigned item,
-                                                float (*prod)[CC][128 + 4]) {
+constexpr int SCAN_PROD = 2;   // producer waves of a scan block (tiles alternate between them)
+
+// producer PI of a scan block: tiles PI, PI + 2, ... -- tile k goes into buffer k & 1 between barriers k - 1 and k
+template <int CC, int CB, int PI>
+__device__ __forceinline__ void splat_scan_producer(const LatticeDev& L, const ValueView& src, unsigned my_k0, unsigned my_k1, unsigned n_steps,
+                                                    int c0, float (*prod)[CB][128 + 4]) {
     constexpr int NH = 2, TE = 128, RE_ = 8, RR_ = 4;
+    constexpr int LW = CB <= 2 ? 2 : 4;              // floats fetched per row: one load instruction
+    static_assert(CB <= 4 && LW <= CC, "class part");
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave > CC) return;
-    const NormItem it = norm_item(L, item);
-    if (!it.ok || it.r >= it.n_vert) return;
-    const unsigned v = L.vorder[(unsigned)it.fs0 + it.r];
-    const unsigned my_k0 = L.vstart[v], my_k1 = L.vend[v];
-    if (my_k1 - my_k0 < L.heavy_from) return;   // (whole block) a regular block's
-    const unsigned n_steps = (my_k1 - my_k0 + (unsigned)TE - 1u) / (unsigned)TE;
-    if (wave == 0) {
-        __builtin_amdgcn_s_setprio(1);
-        float x[RR_][NH][CC];
-        float w[RE_][NH];
-        unsigned pix[RE_][NH];
+    const int ls = c0 + LW <= CC ? c0 : CC - LW;     // the load stays inside the row; the part starts at x[..][c0 - ls]
+    const int xo = c0 - ls;
+    float x[RR_][NH][LW];
+    float w[RE_][NH];
+    unsigned pix[RE_][NH];
 #pragma unroll
-        for (int r = 0; r < RE_; r++)
+    for (int r = 0; r < RE_; r++)
 #pragma unroll
-            for (int h = 0; h < NH; h++) { w[r][h] = 0.f; pix[r][h] = 0u; }
-        // loads are unconditional (indices clamped into the list): no divergent branch, counted waits
-        auto load_entries = [&](unsigned tile, int slot) {
+        for (int h = 0; h < NH; h++) { w[r][h] = 0.f; pix[r][h] = 0u; }
+    // loads are unconditional (indices clamped into the list): no divergent branch, counted waits.  `j` counts this
+    // producer's own tiles: tile 2 j + PI
+    auto load_entries = [&](unsigned j, int slot) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                unsigned k = my_k0 + tile * (unsigned)TE + (unsigned)lane + 64u * h;
-                k = k < my_k1 ? k : my_k1 - 1u;
-                const uint2 pw = L.csr_pw[k];
-                w[slot][h] = __uint_as_float(pw.y);
-                pix[slot][h] = pw.x;
-            }
-        };
-        auto gather_rows = [&](int eslot, int rslot) {
+        for (int h = 0; h < NH; h++) {
+            unsigned k = my_k0 + (2u * j + PI) * (unsigned)TE + (unsigned)lane + 64u * h;
+            k = k < my_k1 ? k : my_k1 - 1u;
+            const uint2 pw = L.csr_pw[k];
+            w[slot][h] = __uint_as_float(pw.y);
+            pix[slot][h] = pw.x;
+        }
+    };
+    auto gather_rows = [&](int eslot, int rslot) {
 #pragma unroll
-            for (int h = 0; h < NH; h++) load_row<CC>(src.base + (size_t)pix[eslot][h] * (unsigned)CC, x[rslot][h]);
-        };
+        for (int h = 0; h < NH; h++) load_row<LW>(src.base + (size_t)pix[eslot][h] * (unsigned)CC + (unsigned)ls, x[rslot][h]);
+    };
 #pragma unroll
-        for (int i = 0; i < RE_ - 1; i++) load_entries((unsigned)i, i);
+    for (int i = 0; i < RE_ - 1; i++) load_entries((unsigned)i, i);
 #pragma unroll
-        for (int i = 0; i < RR_ - 1; i++) gather_rows(i, i);
-        auto stage = [&](unsigned t, auto S) -> bool {
-            constexpr int s = decltype(S)::value;
-            if (t >= n_steps) return false;
+    for (int i = 0; i < RR_ - 1; i++) gather_rows(i, i);
+    // stage j: barriers 2 j and 2 j + 1 of the block (n_steps + 1 in all), this producer's tile before its own one
+    auto stage = [&](unsigned j, auto S) -> bool {
+        constexpr int s = decltype(S)::value;
+        const unsigned t = 2u * j + PI;
+        if (2u * j > n_steps) return false;
+        if (PI == 1) {
+            __syncthreads();                       // barrier 2 j
+            if (t > n_steps) return false;
+        }
+        if (t < n_steps) {
             const unsigned base = my_k0 + t * (unsigned)TE;
             const unsigned n_valid = my_k1 - base < (unsigned)TE ? my_k1 - base : (unsigned)TE;
             float (*pb)[TE + 4] = prod[t & 1u];
@@ -1409,46 +1416,80 @@ __device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const Value
                 const bool in = (unsigned)lane + 64u * h < n_valid;
                 const float wl = in ? w[s][h] : 0.0f;   // +0 past the list: the product is +0, the identity of the sum
 #pragma unroll
-                for (int c = 0; c < CC; c++) pb[c][lane + 64 * h] = wl * x[s % RR_][h][c];
+                for (int c = 0; c < CB; c++) {
+                    // class c0 + c sits at x[c + xo], xo = 0 or 1: a select between two registers, no indexed access
+                    const float xv = xo ? x[s % RR_][h][c + 1 < LW ? c + 1 : c] : x[s % RR_][h][c];
+                    pb[c][lane + 64 * h] = wl * xv;
+                }
             }
-            load_entries(t + RE_ - 1, (s + RE_ - 1) % RE_);
-            gather_rows((s + RR_ - 1) % RE_, (s + RR_ - 1) % RR_);
-            __syncthreads();
-            return true;
-        };
-#define RV_ST(i) if (!stage(t0 + i, std::integral_constant<int, i>())) break;
-        for (unsigned t0 = 0;; t0 += RE_) {
-            RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
         }
+        load_entries(j + RE_ - 1, (s + RE_ - 1) % RE_);
+        gather_rows((s + RR_ - 1) % RE_, (s + RR_ - 1) % RR_);
+        __syncthreads();                           // barrier t
+        if (PI == 0) {
+            if (t + 1u > n_steps) return false;
+            __syncthreads();                       // barrier 2 j + 1
+        }
+        return true;
+    };
+#define RV_ST(i) if (!stage(j0 + i, std::integral_constant<int, i>())) break;
+    for (unsigned j0 = 0;; j0 += RE_) {
+        RV_ST(0) RV_ST(1) RV_ST(2) RV_ST(3) RV_ST(4) RV_ST(5) RV_ST(6) RV_ST(7)
+    }
 #undef RV_ST
-        __syncthreads();
+}
+
+// classes per scan block: the CC classes of a vertex are split over ceil(CC / CB) blocks -- nine adder waves on one CU
+// were bound by instruction issue (0.35 us per 128-entry step); three per block leave a wave per SIMD
+template <int CC> struct ScanPart { static constexpr int CB = CC == 9 ? 3 : 4; static constexpr int NP = (CC + CB - 1) / CB; };
+
+template <int CC>
+__device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const ValueView& src, float* __restrict__ values, unsigned item,
+                                                float (*prod)[ScanPart<CC>::CB][128 + 4]) {
+    constexpr int TE = 128, CB = ScanPart<CC>::CB, NP = ScanPart<CC>::NP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave >= CB + SCAN_PROD) return;
+    const NormItem it = norm_item(L, item / NP);
+    if (!it.ok || it.r >= it.n_vert) return;
+    const unsigned v = L.vorder[(unsigned)it.fs0 + it.r];
+    const unsigned my_k0 = L.vstart[v], my_k1 = L.vend[v];
+    if (my_k1 - my_k0 < L.heavy_from) return;   // (whole block) a regular block's
+    const unsigned n_steps = (my_k1 - my_k0 + (unsigned)TE - 1u) / (unsigned)TE;
+    const int c0 = (int)(item % NP) * CB;       // this block's classes: c0 .. min(c0 + CB, CC) - 1
+    // every wave passes barriers 0 .. n_steps: tile t is complete at barrier t and is summed between barriers t and t + 1
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(1);
+        splat_scan_producer<CC, CB, 0>(L, src, my_k0, my_k1, n_steps, c0, prod);
+    } else if (wave == 1) {
+        __builtin_amdgcn_s_setprio(1);
+        splat_scan_producer<CC, CB, 1>(L, src, my_k0, my_k1, n_steps, c0, prod);
     } else {
         // ---- adder of class c: entries 2 l and 2 l + 1 of a tile in lane l
         __builtin_amdgcn_s_setprio(3);
-        const int c = wave - 1;
+        const int ci = wave - SCAN_PROD, c = c0 + ci;
         float acc = 0.0f;
         __syncthreads();
         for (unsigned t = 0; t < n_steps; t++) {
-            const float2 q = *reinterpret_cast<const float2*>(&prod[t & 1u][c][2 * lane]);
+            const float2 q = *reinterpret_cast<const float2*>(&prod[t & 1u][ci][2 * lane]);
             const float wk[2] = {q.x, q.y};
             acc = ordered_tile_sum<2>(acc, wk);
             __syncthreads();
         }
-        if (lane == 0) values[(size_t)v * CC + c] = acc;
+        if (lane == 0 && c < CC) values[(size_t)v * CC + c] = acc;
     }
 }
 
 // blocks [0, n_scan_items): scan blocks; the rest: regular blocks of GV vertices (their waves beyond GV + 1 leave at once)
 template <int CC, int GV>
-__global__ void __launch_bounds__((CC + 1) * 64)
+__global__ void __launch_bounds__((GV + 1) * 64)
 splat_mixed_kernel(LatticeDev L, ValueView src, float* __restrict__ values, unsigned n_scan_items) {
-    static_assert(GV + 1 <= CC + 1, "block size");
+    static_assert(ScanPart<CC>::CB + SCAN_PROD <= GV + 1, "block size");
     __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][64 * 2 + 4];
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
     if (blockIdx.x < n_scan_items) {
-        splat_scan_item<CC>(L, src, values, blockIdx.x, reinterpret_cast<float (*)[CC][128 + 4]>(&prod[0][0][0][0]));
+        splat_scan_item<CC>(L, src, values, blockIdx.x, reinterpret_cast<float (*)[ScanPart<CC>::CB][128 + 4]>(&prod[0][0][0][0]));
     } else {
-        if ((int)(threadIdx.x >> 6) > GV) return;
         splat_group_item<0, CC, true, GV, true, 2>(L, src, CC, 0, CC, values, blockIdx.x - n_scan_items, prod);
     }
 }
@@ -1460,9 +1501,9 @@ static void splat_mixed_launch(const LatticeDev& L0, const ValueView& src, float
     const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
     const unsigned long long max_heavy = std::min<unsigned long long>(max_mf, (unsigned long long)(L.d + 1) * L.N / SPLAT_HEAVY + 1);
-    const unsigned n_scan = nfg * (unsigned)max_heavy * (unsigned)L.n_groups;
+    const unsigned n_scan = nfg * (unsigned)max_heavy * (unsigned)L.n_groups * (unsigned)ScanPart<CC>::NP;
     const unsigned n_regular = nfg * (unsigned)((max_mf + GV - 1) / GV) * (unsigned)L.n_groups;
-    splat_mixed_kernel<CC, GV><<<dim3(n_scan + n_regular), dim3((CC + 1) * 64), 0, s>>>(L, src, values, n_scan);
+    splat_mixed_kernel<CC, GV><<<dim3(n_scan + n_regular), dim3((GV + 1) * 64), 0, s>>>(L, src, values, n_scan);
     RV_LAUNCHED("splat_mixed_kernel");
 }
 
