@@ -1360,12 +1360,14 @@ static void launch_norm_sum(const LatticeDev& L, float* values, hipStream_t s) {
 constexpr unsigned SPLAT_HEAVY = 16384;   // entries from which a list gets a scan block
 
 constexpr int SCAN_PROD = 2;   // producer waves of a scan block (tiles alternate between them)
+constexpr int SCAN_NH = 4;     // entries per producer lane and tile: tiles of 256 (the adders' lanes take four addends each)
+constexpr int SCAN_TE = 64 * SCAN_NH;
 
 // producer PI of a scan block: tiles PI, PI + 2, ... -- tile k goes into buffer k & 1 between barriers k - 1 and k
 template <int CC, int CB, int PI>
 __device__ __forceinline__ void splat_scan_producer(const LatticeDev& L, const ValueView& src, unsigned my_k0, unsigned my_k1, unsigned n_steps,
-                                                    int c0, float (*prod)[CB][128 + 4]) {
-    constexpr int NH = 2, TE = 128, RE_ = 8, RR_ = 4;
+                                                    int c0, float (*prod)[CB][SCAN_TE + 4]) {
+    constexpr int NH = SCAN_NH, TE = SCAN_TE, RE_ = 8, RR_ = 4;
     constexpr int LW = CB <= 2 ? 2 : 4;              // floats fetched per row: one load instruction
     static_assert(CB <= 4 && LW <= CC, "class part");
     const int lane = threadIdx.x & 63;
@@ -1445,8 +1447,9 @@ template <int CC> struct ScanPart { static constexpr int CB = CC == 9 ? 3 : 4; s
 
 template <int CC>
 __device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const ValueView& src, float* __restrict__ values, unsigned item,
-                                                float (*prod)[ScanPart<CC>::CB][128 + 4]) {
-    constexpr int TE = 128, CB = ScanPart<CC>::CB, NP = ScanPart<CC>::NP;
+                                                float (*prod)[ScanPart<CC>::CB][SCAN_TE + 4]) {
+    constexpr int TE = SCAN_TE, CB = ScanPart<CC>::CB, NP = ScanPart<CC>::NP;
+    static_assert(SCAN_NH == 4, "the adders read float4");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= CB + SCAN_PROD) return;
@@ -1465,15 +1468,15 @@ __device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const Value
         __builtin_amdgcn_s_setprio(1);
         splat_scan_producer<CC, CB, 1>(L, src, my_k0, my_k1, n_steps, c0, prod);
     } else {
-        // ---- adder of class c: entries 2 l and 2 l + 1 of a tile in lane l
+        // ---- adder of class c: entries 4 l .. 4 l + 3 of a tile in lane l
         __builtin_amdgcn_s_setprio(3);
         const int ci = wave - SCAN_PROD, c = c0 + ci;
         float acc = 0.0f;
         __syncthreads();
         for (unsigned t = 0; t < n_steps; t++) {
-            const float2 q = *reinterpret_cast<const float2*>(&prod[t & 1u][ci][2 * lane]);
-            const float wk[2] = {q.x, q.y};
-            acc = ordered_tile_sum<2>(acc, wk);
+            const float4 q = *reinterpret_cast<const float4*>(&prod[t & 1u][ci][4 * lane]);
+            const float wk[4] = {q.x, q.y, q.z, q.w};
+            acc = ordered_tile_sum<4>(acc, wk);
             __syncthreads();
         }
         if (lane == 0 && c < CC) values[(size_t)v * CC + c] = acc;
@@ -1484,11 +1487,11 @@ __device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const Value
 template <int CC, int GV>
 __global__ void __launch_bounds__((GV + 1) * 64)
 splat_mixed_kernel(LatticeDev L, ValueView src, float* __restrict__ values, unsigned n_scan_items) {
-    static_assert(ScanPart<CC>::CB + SCAN_PROD <= GV + 1, "block size");
+    static_assert(ScanPart<CC>::CB + SCAN_PROD <= GV + 1 && 2 * ScanPart<CC>::CB * (SCAN_TE + 4) <= 2 * GV * CC * (64 * 2 + 4), "block size, LDS");
     __shared__ __attribute__((aligned(16))) float prod[2][GV][CC][64 * 2 + 4];
     if (L.counters[1]) return;   // hash overflow (flagged): the CSR arrays are incomplete, touch nothing
     if (blockIdx.x < n_scan_items) {
-        splat_scan_item<CC>(L, src, values, blockIdx.x, reinterpret_cast<float (*)[ScanPart<CC>::CB][128 + 4]>(&prod[0][0][0][0]));
+        splat_scan_item<CC>(L, src, values, blockIdx.x, reinterpret_cast<float (*)[ScanPart<CC>::CB][SCAN_TE + 4]>(&prod[0][0][0][0]));
     } else {
         splat_group_item<0, CC, true, GV, true, 2>(L, src, CC, 0, CC, values, blockIdx.x - n_scan_items, prod);
     }
