@@ -1541,6 +1541,8 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         const int gv = splat_gv_choice(L);
         // six vertices per block go with 128-entry tiles: both serve launches whose time is their longest chain
         // a frame or two, a cloud: the launch waits for its longest chains -- those get scan blocks
+        // (measured with 16 frames of 1280x960, two layers: 65 ms per step with scan blocks against 40 without -- many long
+        // lists at once make them a throughput problem: ~60 instructions per tile and class)
         if (gv == 6 && L.n_frames <= 4 && L.ordered_sum_scan) {
             if (C == 9) splat_mixed_launch<9, 6>(L, src, values, s);
             else splat_mixed_launch<8, 6>(L, src, values, s);
