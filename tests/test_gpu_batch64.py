@@ -61,13 +61,27 @@ def test_batch64_headline_config_matches_oracle_and_single_frame_runs(gpu_ctx_fa
         assert np.abs(marg[i] - wm).max() <= TOL, i
         assert np.array_equal(marg[i], wm), "marginals of frame %d are not bit-identical to the oracle" % i
 
-    # (b) the same frames one at a time on the GPU (chunk of 1: other launch shapes, no XCD groups)
+    # (b) the same frames one at a time on the GPU (chunk of 1: other launch shapes, no XCD groups; the long lists of
+    # such a launch are summed by scan blocks, kernels_crf.hip: splat_scan_item), and again with the serial adder only
     one_ctx = gpu_ctx_factory(max_batch=1, **kw)
     one_ctx.forest_load(blob)
     for i in range(N_FRAMES):
         out = one_ctx.segment_frames(rgb[i:i + 1], depth[i:i + 1], calib, want_posteriors=False)
         assert np.array_equal(out["labels"][0].ravel(), lab[i]), i
         assert np.array_equal(out["marginals"][0], marg[i]), i
+    assert one_ctx.last_schedule()["splat"] == "list-major"
+    serial_ctx = gpu_ctx_factory(max_batch=1, schedule=dict(serial_chains=1), **kw)
+    serial_ctx.forest_load(blob)
+    for i in (0, 9, 63):
+        out = serial_ctx.segment_frames(rgb[i:i + 1], depth[i:i + 1], calib, want_posteriors=False)
+        assert np.array_equal(out["marginals"][0], marg[i]), i
+    # (c) chunks of 3 and 4 frames: scan blocks with several frames per launch (frame order of the items)
+    for n, first in ((3, 5), (4, 40)):
+        few_ctx = gpu_ctx_factory(max_batch=n, **kw)
+        few_ctx.forest_load(blob)
+        out = few_ctx.segment_frames(rgb[first:first + n], depth[first:first + n], calib, want_posteriors=False)
+        assert np.array_equal(out["labels"].reshape(n, -1), lab[first:first + n]), n
+        assert np.array_equal(out["marginals"].reshape(n, -1), marg[first:first + n]), n
 
 
 def test_deep_scene_many_vertices_default_schedule(gpu_ctx_factory, oracle):
