@@ -349,6 +349,8 @@ typedef struct rvseg_schedule {
     int32_t serial_chains;       /* 0 (default): the normaliser's ordered sums by exact wave scans (kernels_crf.hip:
                                     ordered_tile_sum); 1: one dependent addition per entry, like the reference loop.
                                     Results are bit-identical; 1 exists for tests and timing                        */
+    int32_t csr_block;           /* points per wave-block of the counting sort: 0 = by the chunk (256 for <= 8 frames,
+                                    else 1024), or 256 / 512 / 1024 / 2048 / 4096                                     */
 } rvseg_schedule;
 void rvseg_schedule_default(rvseg_schedule *s);
 /* Applies to every later call on ctx (buffers of a schedule are allocated on first use). */

@@ -65,7 +65,7 @@ class RvsegTrainParams(C.Structure):
 class RvsegSchedule(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "splat", "resident_blocks", "resident_band", "resident_chunk", "resident_window", "resident_cap_tiles",
-        "group_vertices", "overlap_build", "overlap_layers", "build_priority_high", "trace", "serial_chains")]
+        "group_vertices", "overlap_build", "overlap_layers", "build_priority_high", "trace", "serial_chains", "csr_block")]
 
 
 class RvsegScheduleInfo(C.Structure):

@@ -425,7 +425,7 @@ void launch_vertex_order(const LatticeDev& L, SortBuffers& sb, hipStream_t s);
 //   scan             per frame: vertex start offsets and per-(wave-block, vertex) bases
 //   pass 2 (scatter) same walk, entries land at base + rank
 // ---------------------------------------------------------------------------------------------
-constexpr int CS_PIX = 256;
+constexpr int CS_PIX_MIN = 256;   // points per wave-block (LatticeDev::cs_pix): 256 .. 4096, a power of two
 constexpr int CS_MCAP = 4096;   // 4 waves x 4096 counters = 64 KB of LDS at the largest fast-path capacity (2^13 slots per frame)
 
 // bh holds, per frame, a dense [wave-block][vertex] matrix with row stride M_f; the frame's matrix
@@ -450,8 +450,8 @@ csr_pass_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     if (Mf == 0 && lane == 0) my[0] = 0xFFFFFFFFu;   // no vertices (overflow only): positions fail the bound check
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int dp1 = L.d + 1;
-    const long long p0 = (long long)wb * CS_PIX;
-    const long long p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const long long p0 = (long long)wb * L.cs_pix;
+    const long long p1 = p0 + L.cs_pix < L.N ? p0 + L.cs_pix : L.N;
     const long long ebeg = ((long long)frame * L.N + p0) * dp1, eend = ((long long)frame * L.N + p1) * dp1;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     // software pipeline: the next chunk's loads are in flight while the current chunk is ranked
@@ -535,8 +535,8 @@ csr_count_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap) {
     for (int lv = lane; lv < Mf; lv += 64) my[lv] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int dp1 = L.d + 1;
-    const long long p0 = (long long)wb * CS_PIX;
-    const long long p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const long long p0 = (long long)wb * L.cs_pix;
+    const long long p1 = p0 + L.cs_pix < L.N ? p0 + L.cs_pix : L.N;
     const long long ebeg = ((long long)frame * L.N + p0) * dp1, eend = ((long long)frame * L.N + p1) * dp1;
     auto fetch = [&](long long e, int (&sl)[4]) {   // slots of entries e .. e + 3 (clamped into the wave-block)
         if (e + 4 <= eend) {
@@ -612,8 +612,8 @@ csr_scatter_kernel(LatticeDev L, const unsigned* __restrict__ bh, int wbpf, int 
     for (int lv = lane; lv < Mf; lv += 64) my[lv] = row[lv];
     if (Mf == 0 && lane == 0) my[0] = 0xFFFFFFFFu;   // no vertices (overflow only): positions fail the bound check
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const int p0 = wb * CS_PIX;
-    const int p1 = p0 + CS_PIX < L.N ? p0 + CS_PIX : L.N;
+    const int p0 = wb * L.cs_pix;
+    const int p1 = p0 + L.cs_pix < L.N ? p0 + L.cs_pix : L.N;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int pc = p0; pc < p1; pc += 64) {
         const int p = pc + lane;
@@ -754,7 +754,7 @@ csr_scan_kernel(LatticeDev L, unsigned* __restrict__ bh, int wbpf, int mcap, int
 
 bool csr_fast_path(const LatticeDev& L) { return ((L.cap_f_mask + 1) / 2) <= (unsigned)CS_MCAP; }
 size_t csr_fast_bytes(const LatticeDev& L) {
-    const size_t wbpf = ((size_t)L.N + CS_PIX - 1) / CS_PIX;
+    const size_t wbpf = ((size_t)L.N + L.cs_pix - 1) / L.cs_pix;
     // the [wave-block][vertex] matrices of all frames, then per vertex its column total and CS_SEGS segment sums
     return (wbpf * ((size_t)L.m_bound + 64) + (size_t)L.m_bound * (1 + CS_SEGS)) * sizeof(unsigned);
 }
@@ -772,7 +772,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     RV_LAUNCHED("lattice_compact_kernel / lattice_neighbours_kernel");
     if (csr_fast_path(L) && sb.block_hist) {
         const int mcap = (int)((L.cap_f_mask + 1) / 2);
-        const int wbpf = (L.N + CS_PIX - 1) / CS_PIX;
+        const int wbpf = (L.N + L.cs_pix - 1) / L.cs_pix;
         const long long waves = (long long)wbpf * L.n_frames;
         const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
         const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
@@ -2144,7 +2144,7 @@ static bool splat_resident_launch(const LatticeDev& L, const SplatResidentDev& R
     return hipGetLastError() == hipSuccess;   // a refused launch is a refused set-up: fall back
 }
 
-int csr_pix_per_block() { return CS_PIX; }
+int csr_pix_min() { return CS_PIX_MIN; }
 
 // ---------------------------------------------------------------------------------------------
 // blur along one lattice axis (permutohedral.cpp:556-569 / :496-510)

@@ -230,7 +230,8 @@ rvseg_status rvseg_set_schedule(rvseg_ctx* ctx, const rvseg_schedule* s) {
     if (!ctx) return RVSEG_ERR_INVALID_ARG;
     if (!s || s->splat < 0 || s->splat > 2 || s->resident_blocks < 0 || s->resident_blocks > 16 || s->resident_band < 1 ||
         (s->resident_chunk != 64 && s->resident_chunk != 128) || s->resident_cap_tiles < 0 ||
-        (s->group_vertices != 0 && s->group_vertices != 6 && s->group_vertices != 7)) {
+        (s->group_vertices != 0 && s->group_vertices != 6 && s->group_vertices != 7) ||
+        (s->csr_block != 0 && s->csr_block != 256 && s->csr_block != 512 && s->csr_block != 1024 && s->csr_block != 2048 && s->csr_block != 4096)) {
         ctx->err = "bad schedule";
         return RVSEG_ERR_INVALID_ARG;
     }

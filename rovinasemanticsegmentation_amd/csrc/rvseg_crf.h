@@ -36,6 +36,7 @@ struct LatticeDev {
     int n_groups;                // 8 when the chunk has >= 8 frames, else 1
     int group_vertices;          // list-major walk, C = 8 / 9: vertices per block (0 = by the chunk's shape, 6, 7)
     int ordered_sum_scan;        // normaliser: exact wave-scan sums (1) or the serial chain (0); same bits either way
+    int cs_pix;                  // counting sort: points per wave-block (256 for launches of <= 8 frames, else 1024)
     unsigned heavy_from;         // list-major walk: lists of this many entries and more belong to scan blocks (0 = none)
     // counting-sort path: after the scan, bh[wave-block][vertex] is the position of the vertex's first entry at or
     // after that wave-block, i.e. the vertex-major lists can be cut at any multiple of CS_PIX points without
@@ -115,7 +116,7 @@ size_t sort_temp_bytes(long long n_entries, int key_bits);
 size_t scan_temp_bytes(unsigned cap);
 bool csr_fast_path(const LatticeDev& L);
 size_t csr_fast_bytes(const LatticeDev& L);
-int csr_pix_per_block();
+int csr_pix_min();
 void launch_csr_norm(const LatticeDev& L, long long n_entries, hipStream_t s);
 // mode 0: in = src; 1: in = fl(src * norm); 2: in = 1
 // own_q: src is the mean-field loop's own Q * norm (finite, non-negative): enables the select-free producer

@@ -185,11 +185,17 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.group_vertices = ctx->sched.group_vertices;
     L.ordered_sum_scan = ctx->sched.serial_chains ? 0 : 1;
     L.heavy_from = 0;
+    // Wave-blocks of the counting sort.  Its [wave-block][vertex] count matrix is written once and read three times, and
+    // its size is points / cs_pix x vertices: 1024-point blocks cut a 64-frame step by 0.15 ms (deep scene: 1.3 ms; 32
+    // frames 0.16, 16 frames 0.11), but a single frame then has only 300 waves to sort with (+0.07 ms) and 8 frames
+    // gain nothing, so small launches keep 256 (sweep of 256 .. 4096 over 8 - 64 frames: scratch-style script in
+    // DESIGN.md section 4; results are identical for every size)
+    L.cs_pix = ctx->sched.csr_block > 0 ? ctx->sched.csr_block : (n_frames <= 8 ? 256 : 1024);
     if (csr_fast_path(L)) {
         if ((st = dev_reserve(ctx, b.block_hist, csr_fast_bytes(L))) != RVSEG_OK) return st;
         b.sb.block_hist = b.block_hist.as<unsigned>();
         L.bh = b.sb.block_hist;
-        L.wbpf = (N + csr_pix_per_block() - 1) / csr_pix_per_block();
+        L.wbpf = (N + L.cs_pix - 1) / L.cs_pix;
     }
     b.n_entries = E; b.n_points = P;
     b.built = false;
@@ -210,10 +216,11 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
         if (sc.resident_blocks <= 0) B = B < 2 ? 2 : (B > 12 ? 12 : B);
         B = B > RES_MAXB ? RES_MAXB : B;
         if (wanted && L.bh && d == 6 && B >= 2 && (long long)n_frames * B <= capacity &&
-            7ll * N < (1ll << 24) && (long long)L.wbpf <= 32ll * RES_MAX_BANDS) {   // (bands stay under 64 wave-blocks: chunk counts fit 8 bits)
+            7ll * N < (1ll << 24) && (long long)L.wbpf * L.cs_pix <= 8192ll * RES_MAX_BANDS && L.cs_pix <= 4096) {   // (bands stay under 16 384 points: chunk counts fit 8 bits)
             SplatResidentDev& R = b.resident;
             R.B = B;
             R.band_wb = sc.resident_band < 1 ? 1 : (sc.resident_band > 32 ? 32 : sc.resident_band);
+            R.band_wb = std::max(1, R.band_wb * 256 / L.cs_pix);   // rvseg_schedule.resident_band counts 256 points
             R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb;
             while (R.n_bands > RES_MAX_BANDS) { R.band_wb *= 2; R.n_bands = (L.wbpf + R.band_wb - 1) / R.band_wb; }
             R.window = sc.resident_window;

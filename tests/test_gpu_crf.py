@@ -308,6 +308,33 @@ def test_resident_band_splat_falls_back_when_the_planner_gives_up(gpu_ctx_factor
         assert np.array_equal(out["marginals"][i], marg), i
 
 
+@pytest.mark.parametrize("csr_block,splat", [(256, 2), (512, 1), (1024, 2), (2048, 2), (4096, 1), (4096, 2)])
+def test_counting_sort_block_sizes(gpu_ctx_factory, oracle, csr_block, splat):
+    """rvseg_schedule.csr_block: the counting sort's wave-blocks of 256 .. 4096 points (the library takes 256 for
+    launches of <= 8 frames, 1024 otherwise).  The lists -- and the bands the resident schedule cuts them into -- are
+    the same for every size, so the marginals are the oracle's to the bit; 6 frames of 320 x 200 = 64 000 points, which
+    no block size divides."""
+    blob = synthetic.make_forest_bytes(seed=33, n_trees=3, leaves_per_tree=256, max_depth=12, single_classes=9, layer_classes=(8, 9))
+    forest = oracle.Forest(blob)
+    W, H, n = 320, 200, 6
+    rgb, depth = synthetic.make_batch(n, W, H, holes=True, start=2)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, dcrf_iterations=3)
+    p = oracle.default_params(**kw)
+    ctx = gpu_ctx_factory(multi_layer=0, use_dense_crf=1, label_mode=1, unknown_label=[8], max_batch=n,
+                          schedule=dict(splat=splat, csr_block=csr_block), **kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(rgb, depth, calib)
+    assert ctx.last_schedule()["splat"] == ("resident" if splat == 2 else "list-major")
+    assert ctx.last_schedule()["planner_fallback"] == 0
+    for i in range(n):
+        post, marg, lab = oracle.segment_frame(p, forest, 0, rgb[i], depth[i], calib, label_mode=1, unknown=[8])
+        assert np.array_equal(out["marginals"][i], marg), i
+        assert np.array_equal(out["labels"][i].ravel(), lab), i
+    with pytest.raises(Exception):
+        ctx.set_schedule(csr_block=300)
+
+
 @pytest.mark.parametrize("scale,B", [(1.0, 4), (3.0, 4), (3.0, 2)])
 def test_resident_band_splat_two_layers_and_fine_lattices(gpu_ctx_factory, oracle, scale, B):
     """The resident schedule for the 8-class layer too (two label layers: an 8- and a 9-class mean field over one
