@@ -929,7 +929,7 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             if (idx < n_vert) {
                 const unsigned v = L.vorder[gstart + idx];
                 const unsigned k0 = L.vstart[v], k1 = L.vend[v];
-                if (L.heavy_from && k1 - k0 >= L.heavy_from) continue;   // a scan block's (splat_scan_item)
+                if (idx < L.scan_ranks && k1 - k0 >= L.heavy_from) continue;   // a scan block's (splat_scan_item)
                 const unsigned nt = (k1 - k0 + (unsigned)TE - 1u) / (unsigned)TE;
                 n_steps = nt > n_steps ? nt : n_steps;
                 if (i == pw && wave != AW) { my_k0 = k0; my_k1 = k1; }
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void splat_group_item(const LatticeDev& L, const Valu
             const unsigned idx = r * G + gi;
             bool mine = lane < G * CC && idx < n_vert && c < n_store;
             const unsigned cv = mine ? L.vorder[gstart + idx] : 0u;
-            if (mine && L.heavy_from && L.vend[cv] - L.vstart[cv] >= L.heavy_from) mine = false;   // a scan block's
+            if (mine && idx < L.scan_ranks && L.vend[cv] - L.vstart[cv] >= L.heavy_from) mine = false;   // a scan block's
             float acc = 0.0f;
             __syncthreads();
             for (unsigned t = 0; t < n_steps; t++) {
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void splat_scan_item(const LatticeDev& L, const Value
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave >= CB + SCAN_PROD) return;
     const NormItem it = norm_item(L, item / NP);
-    if (!it.ok || it.r >= it.n_vert) return;
+    if (!it.ok || it.r >= it.n_vert || it.r >= L.scan_ranks) return;
     const unsigned v = L.vorder[(unsigned)it.fs0 + it.r];
     const unsigned my_k0 = L.vstart[v], my_k1 = L.vend[v];
     if (my_k1 - my_k0 < L.heavy_from) return;   // (whole block) a regular block's
@@ -1503,8 +1503,14 @@ static void splat_mixed_launch(const LatticeDev& L0, const ValueView& src, float
     L.heavy_from = SPLAT_HEAVY;
     const unsigned nfg = ((unsigned)L.n_frames + (unsigned)L.n_groups - 1u) / (unsigned)L.n_groups;
     const unsigned long long max_mf = std::min<unsigned long long>(((unsigned long long)L.cap_f_mask + 1) / 2 + 1, (unsigned long long)L.m_bound);
+    // a frame of N points has at most 7 N / SPLAT_HEAVY lists that long; and only as many ranks per frame as give every
+    // scan block a CU of its own -- they are there to shorten the launch's longest chains, and cost ~60 instructions
+    // per tile and class where the serial adder costs ~10, so a second round of them is a loss (measured: 8 - 16 frames
+    // with a scan block for EVERY long list ran 4 - 28 % slower than without any)
     const unsigned long long max_heavy = std::min<unsigned long long>(max_mf, (unsigned long long)(L.d + 1) * L.N / SPLAT_HEAVY + 1);
-    const unsigned n_scan = nfg * (unsigned)max_heavy * (unsigned)L.n_groups * (unsigned)ScanPart<CC>::NP;
+    const unsigned ranks_by_cus = (unsigned)resident_cu_count() / ((unsigned)ScanPart<CC>::NP * (unsigned)std::max(1, L.n_frames));
+    L.scan_ranks = (unsigned)std::min<unsigned long long>(max_heavy, std::max(1u, ranks_by_cus));
+    const unsigned n_scan = nfg * L.scan_ranks * (unsigned)L.n_groups * (unsigned)ScanPart<CC>::NP;
     const unsigned n_regular = nfg * (unsigned)((max_mf + GV - 1) / GV) * (unsigned)L.n_groups;
     splat_mixed_kernel<CC, GV><<<dim3(n_scan + n_regular), dim3((GV + 1) * 64), 0, s>>>(L, src, values, n_scan);
     RV_LAUNCHED("splat_mixed_kernel");
@@ -1540,10 +1546,8 @@ void launch_splat(const LatticeDev& L, const ValueView& src, int C, int mode, fl
         // block shape chosen for the chunk
         const int gv = splat_gv_choice(L);
         // six vertices per block go with 128-entry tiles: both serve launches whose time is their longest chain
-        // a frame or two, a cloud: the launch waits for its longest chains -- those get scan blocks
-        // (measured with 16 frames of 1280x960, two layers: 65 ms per step with scan blocks against 40 without -- many long
-        // lists at once make them a throughput problem: ~60 instructions per tile and class)
-        if (gv == 6 && L.n_frames <= 4 && L.ordered_sum_scan) {
+        // launches of <= 16 frames wait for their longest chains: those get scan blocks, as many as there are CUs
+        if (gv == 6 && L.ordered_sum_scan) {
             if (C == 9) splat_mixed_launch<9, 6>(L, src, values, s);
             else splat_mixed_launch<8, 6>(L, src, values, s);
             return;

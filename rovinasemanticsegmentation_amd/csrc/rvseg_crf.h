@@ -37,7 +37,8 @@ struct LatticeDev {
     int group_vertices;          // list-major walk, C = 8 / 9: vertices per block (0 = by the chunk's shape, 6, 7)
     int ordered_sum_scan;        // normaliser: exact wave-scan sums (1) or the serial chain (0); same bits either way
     int cs_pix;                  // counting sort: points per wave-block (256 for launches of <= 8 frames, else 1024)
-    unsigned heavy_from;         // list-major walk: lists of this many entries and more belong to scan blocks (0 = none)
+    unsigned heavy_from;         // list-major walk: lists of this many entries and more belong to scan blocks (0 = none) ...
+    unsigned scan_ranks;         // ... if they are among the scan_ranks longest of their frame
     // counting-sort path: after the scan, bh[wave-block][vertex] is the position of the vertex's first entry at or
     // after that wave-block, i.e. the vertex-major lists can be cut at any multiple of CS_PIX points without
     // another sort (the resident band schedule does)

@@ -185,6 +185,7 @@ static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N
     L.group_vertices = ctx->sched.group_vertices;
     L.ordered_sum_scan = ctx->sched.serial_chains ? 0 : 1;
     L.heavy_from = 0;
+    L.scan_ranks = 0;
     // Wave-blocks of the counting sort.  Its [wave-block][vertex] count matrix is written once and read three times, and
     // its size is points / cs_pix x vertices: 1024-point blocks cut a 64-frame step by 0.15 ms (deep scene: 1.3 ms; 32
     // frames 0.16, 16 frames 0.11), but a single frame then has only 300 waves to sort with (+0.07 ms) and 8 frames
