@@ -37,6 +37,33 @@ def test_params_default_match_reference_config():
     assert p.use_dense_crf == 0                                      # config.json:81
 
 
+def test_schedule_struct_mirrors_the_header_field_by_field():
+    """rvseg_schedule / rvseg_schedule_info in _capi.py against include/rvseg.h (names, order, count), and the defaults the
+    header documents -- rvseg_schedule_default is host-only, so this runs without a GPU."""
+    import ctypes as C
+    import re
+    from rovinasemanticsegmentation_amd import _capi as capi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rvseg.h")).read()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in re.findall(r"int32_t\s+([^;]+);", body):
+            names += [n.strip() for n in decl.split(",")]
+        return names
+    assert [f[0] for f in capi.RvsegSchedule._fields_] == fields("rvseg_schedule")
+    assert [f[0] for f in capi.RvsegScheduleInfo._fields_] == fields("rvseg_schedule_info")
+    sc = capi.RvsegSchedule()
+    for f, _ in capi.RvsegSchedule._fields_:
+        setattr(sc, f, 77)
+    capi.lib().rvseg_schedule_default(C.byref(sc))
+    got = {f: getattr(sc, f) for f, _ in capi.RvsegSchedule._fields_}
+    want = dict.fromkeys(got, 0)
+    want.update(resident_band=16, resident_chunk=128, resident_window=-1, overlap_build=1, overlap_layers=1)
+    assert got == want
+
+
 def test_create_without_gpu_fails_loudly():
     capi = _lib()
     try:
