@@ -1521,7 +1521,9 @@ static int splat_gv_choice(const LatticeDev& L) {
     if (L.group_vertices == 6 || L.group_vertices == 7) return L.group_vertices;
     // few frames: the launch waits for its longest chains (steps x step time), so the shorter step wins;
     // many frames: the launch is bound by the bytes it moves, the block count only adds overhead
-    return L.n_frames <= 16 ? 6 : 7;
+    // (with scan blocks for the longest lists the six-vertex shape wins up to 24 frames: 20 frames 5.12 vs 5.48 ms per
+    // step, 24 frames 5.49 vs 5.98; 32 frames 7.15 vs 7.37 -- but there the resident bands take 7.03)
+    return L.n_frames <= 24 ? 6 : 7;
 }
 
 template <int CC>

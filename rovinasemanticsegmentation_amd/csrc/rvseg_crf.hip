@@ -113,11 +113,12 @@ static bool capacity_is_worst_case(const rvseg_ctx* ctx, int N, int d) {
 // frame (the flat synthetic scene): between 16 and 32 frames (resident 5.14 / 7.53 / 12.59 ms against 4.85 / 7.94 /
 // 13.97 at 16 / 32 / 64 frames); ~2 320 vertices per frame (the deep scene): between 32 and 64 frames (12.35 / 18.70
 // against 10.52 / 19.22).  A line through the two crossovers: resident from 5.6 M points + 4 900 points per vertex of a
-// frame.  The vertex count is a MEASURED quantity: that of the context's previous lattice build (read back with its
+// frame -- moved to 6.9 M + 4 900 per vertex when the list-major walk got scan blocks for its longest lists (24 flat
+// frames: list-major 5.49 ms against 6.04 resident; 32 frames: 7.15 against 7.03).  The vertex count is a MEASURED quantity: that of the context's previous lattice build (read back with its
 // status); before any build has been seen, the flat scene's.
 static bool resident_pays(int n_frames, int N, int vertices_per_frame_seen) {
     const long long vpf = vertices_per_frame_seen > 0 ? vertices_per_frame_seen : 360;
-    return n_frames >= 2 && (long long)n_frames * N >= 5600000ll + 4900ll * vpf;
+    return n_frames >= 2 && (long long)n_frames * N >= 6900000ll + 4900ll * vpf;
 }
 
 static rvseg_status lattice_prepare(rvseg_ctx* ctx, LatticeBufs& b, int d, int N, int n_frames, bool safe, int vertices_per_frame_seen = 0) {
