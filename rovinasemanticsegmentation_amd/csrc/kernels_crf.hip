@@ -1124,6 +1124,22 @@ __device__ __forceinline__ unsigned wave_total_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_term_keep(unsigned v) {   // the DPP-selected lane's v, ~0 where the pattern selects none
+    return (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// minimum over the wave, the same value in every lane
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned t;
+    t = dpp_term_keep<0x111, 0xf>(v); v = t < v ? t : v;
+    t = dpp_term_keep<0x112, 0xf>(v); v = t < v ? t : v;
+    t = dpp_term_keep<0x114, 0xf>(v); v = t < v ? t : v;
+    t = dpp_term_keep<0x118, 0xf>(v); v = t < v ? t : v;
+    t = dpp_term_keep<0x142, 0xa>(v); v = t < v ? t : v;
+    t = dpp_term_keep<0x143, 0xc>(v); v = t < v ? t : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // One attempt at the lanes `mine` (K addends per lane, lane l holding entries K l .. K l + K - 1 of the tile): true and
 // s advanced if the conditions above hold for them, false and s untouched otherwise.
 template <int K>
@@ -1676,18 +1692,29 @@ resident_plan_kernel(LatticeDev L, SplatResidentDev R, int heavy_cap) {
     }
     __syncthreads();
     if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
-    // ---- the rest: fewest tiles so far, a vertex priced at chunks / 7 (sevenths of a tile in `cur7`)
-    if (tid == 0) {
-        unsigned cur7[RES_MAXB];
-        for (int j = 0; j < B; j++) { cur7[j] = cur[j] * 7u; nheavy[j] = nown[j]; }
+    // ---- the rest: fewest tiles so far, a vertex priced at chunks / 7 (sevenths of a tile).  One wave, lane j = block j:
+    // the running prices live in registers and the cheapest block is a DPP minimum (until round 3 thread 0 walked a
+    // private array -- scratch memory -- through this loop: 0.6 ms of the deep scene's 2.8 ms planner, 2 159 light vertices)
+    if (wave == 0) {
+        const bool blk = lane < B;
+        unsigned price = blk ? cur[lane] * 7u : 0xFFFFFFFFu;
+        unsigned cnt = blk ? nown[lane] : 0u;
+        if (blk) nheavy[lane] = cnt;
         for (int k = n_heavy; k < Mf; k++) {
             const int lv = lvo[k];
-            int best = -1;
-            for (int j = 0; j < B; j++) if (nown[j] < (unsigned)RES_MAX_OWNV && (best < 0 || cur7[j] < cur7[best])) best = j;
-            if (best < 0 || lv < 0 || lv >= Mf) { bad = 1; break; }
-            cur7[best] += chv[lv] + 1u;
-            own[best][nown[best]++] = (unsigned short)lv;
+            const bool room = blk && cnt < (unsigned)RES_MAX_OWNV;
+            const unsigned cand = room ? price : 0xFFFFFFFFu;
+            const unsigned best_price = wave_min_u32(cand);
+            const unsigned long long at = __ballot(room && cand == best_price);
+            if (!at || lv < 0 || lv >= Mf) { if (lane == 0) bad = 1; break; }
+            const int best = __ffsll((long long)at) - 1;      // the lowest block among equals, as the serial loop chose
+            if (lane == best) {
+                price += chv[lv] + 1u;
+                own[best][cnt] = (unsigned short)lv;
+                cnt++;
+            }
         }
+        if (blk) nown[lane] = cnt;
     }
     __syncthreads();
     if (bad) { if (tid == 0) atomicAdd(&R.flags[0], 1); return; }
