@@ -106,17 +106,20 @@ prep_kernel(FrameGeom g, LabCoeffs lc, const uint16_t* __restrict__ gamma, const
 // smoothing-window map.  PCL computes a depth-change map, then a two-pass raster chamfer distance
 // (steps 1.0 / 1.4 in float), then window = int(min(distance, 10)) (NaN normal when <= 2).
 // The raster passes are sequential over the whole image; only distances below 10 matter and every
-// step costs >= 1, so a pixel's value is decided inside its 21x21 neighbourhood.  Each workgroup
-// (one wave) therefore re-runs both raster passes on its tile plus a 20-pixel apron held in LDS,
-// sweeping anti-diagonals t = 2*row + col so that all four already-final neighbours of a cell
-// are available.  The float additions follow the raster order exactly, so the result equals the
-// sequential algorithm wherever it is below 10 (and is >= 10 wherever that is).
+// step costs >= 1, so a pixel's value is decided inside its 19x19 neighbourhood: a value below 10 is the float sum
+// along a path of at most 9 steps from a depth-change pixel -- forward steps (first pass: from the left / upper
+// neighbours), then backward steps (second pass) -- and every pixel of such a path lies within 9 pixels of its end.
+// Re-running both passes on a tile plus an apron therefore gives the image-wide result wherever that is below 10, and
+// something >= 10 wherever it is not (restricting the region only removes paths).  Each workgroup (one wave) does
+// that for its tile plus a 10-pixel apron held in LDS, sweeping anti-diagonals t = 2*row + col so that all four
+// already-final neighbours of a cell are available.  The float additions follow the raster order exactly.
+// (Until the end of round 3 the apron was 20 pixels -- the reach of a forward path plus that of a backward path, added
+// up although they share the 9 steps: 25 % of a tile's cells were its own pixels, now 55 %: 0.74 -> 0.38 ms.)
 // ---------------------------------------------------------------------------------------------
-// Tile shape: 24 rows + apron = 64 table rows = one lane per row with no lane idle (16 rows, 56 lanes until round 3:
-// 1.05 -> 0.94 ms for 64 frames with holes), 80 columns (0.75 ms: 31 KB of LDS, still five waves per CU; 96 columns
-// 0.91 ms with four, 128 columns 1.1 ms with three).
-constexpr int DM_TW = 80, DM_TH = 24, DM_APRON = 20;
-constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 120
+// Tile shape: 44 rows + apron = 64 table rows = one lane per row with no lane idle; 80 columns (26 KB of LDS: six
+// waves per CU; 108 and 128 columns measured 0.54 and 0.47 ms against 0.38).
+constexpr int DM_TW = 80, DM_TH = 44, DM_APRON = 10;
+constexpr int DM_CW = DM_TW + 2 * DM_APRON;  // 100
 // row pitch of the LDS table.  Lane l touches row l at column t - 2l, i.e. word (pitch - 2) * l + t: with pitch 104
 // lanes l and l + 16 of a 32-lane group met in one bank (PMC: 62 % of the LDS-active cycles were conflict cycles);
 // an odd multiplier spreads a group over all 32 banks

@@ -32,6 +32,32 @@ def test_extract_features_full_frame_with_holes(gpu_ctx_factory, oracle):
     assert (want[:, 365] == -2).any() and (want[:, 365] > 0).any()
 
 
+@pytest.mark.parametrize("density,seed", [(0.002, 1), (0.004, 2), (0.01, 3), (0.0005, 4)])
+def test_smoothing_window_map_with_isolated_depth_edges(gpu_ctx_factory, oracle, density, seed):
+    """The smoothing-window map comes from a two-pass raster chamfer distance over the whole image; the kernel re-runs
+    both passes per 80 x 44 tile with a 10-pixel apron (kernels_features.hip: window_map_kernel), which is exact because
+    a distance below 10 is a path of at most 9 steps.  Isolated invalid pixels on a smooth surface put most of the image
+    at distances of 3 .. 15 from the nearest depth edge -- every window size, and sources just inside and just outside
+    the apron, at every tile seam -- and the normal feature (window sums over that window) has to equal the oracle's
+    bit for bit at stride 1, i.e. at every pixel."""
+    W, H = 640, 480
+    rng = np.random.default_rng(seed)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ys, xs = np.mgrid[0:H, 0:W]
+    depth = (2000 + 3 * xs + 2 * ys + 40 * np.sin(xs / 37.0) * np.cos(ys / 23.0)).astype(np.uint16)
+    depth[rng.random((H, W)) < density] = 0
+    kw = dict(width=W, height=H, stride=1, feature_color_patch=0, feature_depth=0, feature_height=0)
+    calib = synthetic.make_calib(W, H)
+    want, wx, wy = oracle.extract(oracle.default_params(**kw), rgb, depth, calib)
+    ctx = gpu_ctx_factory(**kw)
+    got, gx, gy = ctx.extract_features(rgb, depth, calib)
+    assert np.array_equal(gx, wx) and np.array_equal(gy, wy)
+    assert got.shape == want.shape and want.shape[1] == 1
+    assert np.array_equal(got, want)
+    valid = want[:, 0] > -2
+    assert 0.2 < valid.mean() < 0.999
+
+
 @pytest.mark.parametrize("stride,patch,r", [(1, 7, 3), (2, 9, 4), (4, 5, 2)])
 def test_extract_features_small_configs(gpu_ctx_factory, oracle, stride, patch, r):
     W, H = 96, 64
