@@ -330,7 +330,7 @@ normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const u
 
 // ---------------------------------------------------------------------------------------------
 // LDS-tiled variant: a block owns 8 x 16 sample points.  The fixed-point gradients of its pixel tile
-// (+ 6-px apron) are formed once, cooperatively, and turned into a two-dimensional prefix sum
+// (+ 5-px apron) are formed once, cooperatively, and turned into a two-dimensional prefix sum
 // (summed-area table) IN PLACE: a window sum is then four corner reads per channel instead of up to
 // 10 x 10 cells -- the integral-image evaluation PCL itself uses (feature_extractor.h:256-261), here
 // on exact 2^-32 fixed-point int64 (order free, and exact modulo 2^64 even if a clamped outlier made
@@ -338,7 +338,7 @@ normal_feature_kernel(FrameGeom g, const float4* __restrict__ cloud_all, const u
 //   table: 7 planes x (th + 1) x (tw + 1) 8-byte cells, row 0 / column 0 are zero;
 //          planes 0..5 = gx0 gx1 gx2 gy0 gy1 gy2, plane 6 = {count_x, count_y} as two int32
 // ---------------------------------------------------------------------------------------------
-constexpr int NF_TY = 8, NF_TX = 16, NF_APRON = 6;
+constexpr int NF_TY = 8, NF_TX = 16, NF_APRON = 5;   // a window of <= 10 cells reaches 5 to the left / up of its sample point and 4 to the right / down
 constexpr int NF_PARTS = 4;     // lanes per sample point: three take two gradient planes each, one the counts
 constexpr int NF_PLANES = 7;
 constexpr int NF_THREADS = NF_TY * NF_TX * NF_PARTS;
