@@ -493,7 +493,7 @@ void launch_normal_feature(const FrameGeom& g, const float4* d_cloud, const uint
     // 5.5 ms and became the critical path: 13.74 vs 13.38 ms per step.  The two branches share the chip work for
     // work; only less work helps.  Removed.)
     const size_t lds = (size_t)(tw + 1) * (th + 1) * NF_PLANES * 8;
-    if (lds <= 80 * 1024) {   // stride <= 2 (73 KB: two tiles per CU); larger strides use the gather kernel
+    if (lds <= 80 * 1024) {   // stride <= 2 (65 KB: two tiles per CU); larger strides use the gather kernel
         static bool attr_set[64] = {};   // per device: more than the default 64 KB of dynamic LDS has to be asked for
         int dev = 0;
         (void)hipGetDevice(&dev);
