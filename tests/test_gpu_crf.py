@@ -432,3 +432,25 @@ def test_config5_chunk_resident_schedule_equals_list_major_walk(gpu_ctx_factory,
     _, marg, lab = oracle.segment_frame(p, forest, 1, rgb[5], depth[5], calib, label_mode=1, unknown=[7, 8])
     assert np.array_equal(results[0][0][5].cpu().numpy(), marg)
     assert np.array_equal(results[0][1][5].cpu().numpy(), lab)
+
+
+def test_one_large_frame_two_layers_scan_blocks_on_two_streams(gpu_ctx_factory, oracle):
+    """One 1280x960 frame with two label layers: the 8- and the 9-class mean field run side by side on two streams, both
+    through the list-major launch whose longest lists (here up to ~3 x 10^5 entries) go to scan blocks -- two adder waves
+    shapes (classes split 4 + 4 and 3 + 3 + 3), producers alternating over 256-entry tiles.  Marginals and labels of
+    both layers against the CPU oracle, bit for bit; and the same call with the serial adder only."""
+    W, H = 1280, 960
+    blob = synthetic.make_forest_bytes(seed=29, n_trees=4, leaves_per_tree=512, max_depth=14)
+    rgb, depth = synthetic.make_batch(1, W, H, holes=True, start=7)
+    calib = synthetic.make_calib(W, H)
+    kw = dict(width=W, height=H, multi_layer=1, use_dense_crf=1, dcrf_iterations=4, label_mode=1, unknown_label=[7, 8], max_batch=1)
+    forest = oracle.Forest(blob)
+    p = oracle.default_params(width=W, height=H, dcrf_iterations=4)
+    _, marg, lab = oracle.segment_frame(p, forest, 1, rgb[0], depth[0], calib, label_mode=1, unknown=[7, 8])
+    for serial in (0, 1):
+        ctx = gpu_ctx_factory(schedule=dict(serial_chains=serial), **kw)
+        ctx.forest_load(blob)
+        out = ctx.segment_frames(rgb, depth, calib, want_posteriors=False)
+        assert ctx.last_schedule()["splat"] == "list-major" and ctx.last_schedule()["longest_list"] >= 16384
+        assert np.array_equal(out["marginals"][0], marg), serial
+        assert np.array_equal(out["labels"][0].ravel(), lab), serial
