@@ -182,6 +182,26 @@ def test_rf_frames_strides_and_feature_toggles(gpu_ctx_factory, oracle, stride, 
     assert np.array_equal(out["posteriors"][0], want)
 
 
+@pytest.mark.parametrize("stride,W,H", [(1, 128, 64), (2, 192, 68), (4, 256, 128), (2, 64, 32)])
+def test_upsampling_through_lds_tiles_other_scales(gpu_ctx_factory, oracle, stride, W, H):
+    """Images whose width is a multiple of 64 and height a multiple of 4 are up-sampled by the tiled kernel
+    (kernels_rf.hip: upsample_pack_tiled_kernel: 64 x 4 output pixels per block through LDS); strides 1, 2 and 4 give it
+    source windows of 66, 34 and 18 columns, with the clamped first / last rows and the `tail` column of cv::resize at
+    the borders.  Posteriors of both label layers (8 and 9 classes) against the oracle, bit for bit."""
+    rgb, depth = _small_case(stride + W, W, H)
+    kw = dict(width=W, height=H, stride=stride, patch_size=9, patch_size_reduce=3)
+    D = oracle.feature_length(oracle.default_params(**kw))
+    blob = synthetic.make_forest_bytes(seed=13, n_trees=4, leaves_per_tree=64, max_depth=9, D=D)
+    forest = oracle.Forest(blob)
+    calib = synthetic.make_calib(W, H)
+    ctx = gpu_ctx_factory(**kw)
+    ctx.forest_load(blob)
+    out = ctx.segment_frames(np.stack([rgb, rgb[::-1].copy()]), np.stack([depth, depth[::-1].copy()]), calib)
+    for i, (r, d) in enumerate(((rgb, depth), (rgb[::-1].copy(), depth[::-1].copy()))):
+        want, _ = oracle.rf_frame(oracle.default_params(**kw), forest, 1, r, d, calib)
+        assert np.array_equal(out["posteriors"][i], want), i
+
+
 def test_lazy_walk_touches_every_feature(gpu_ctx_factory, oracle):
     """The production kernel (rf_frames_lazy_kernel) computes a patch value only when a node tests it, so
     a small forest exercises a small part of the 363 cells.  64 trees x 512 leaves = 32 704 inner nodes:
