@@ -759,7 +759,24 @@ size_t csr_fast_bytes(const LatticeDev& L) {
     return (wbpf * ((size_t)L.m_bound + 64) + (size_t)L.m_bound * (1 + CS_SEGS)) * sizeof(unsigned);
 }
 
-void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s) {
+// phase 0: everything; 1: everything but the scatter of the counting-sort path (vertex numbering, neighbours, counts,
+// list bounds, launch order: all the splat planner needs); 2: that scatter.  (The radix-sort path does it all in 0 / 1.)
+void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s, int phase) {
+    const bool fast = csr_fast_path(L) && sb.block_hist;
+    if (phase == 2) {
+        if (!fast) return;
+        const int mcap = (int)((L.cap_f_mask + 1) / 2);
+        const int wbpf = (L.N + L.cs_pix - 1) / L.cs_pix;
+        const long long waves = (long long)wbpf * L.n_frames;
+        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        const size_t lds = (size_t)4 * mcap * sizeof(unsigned);
+        if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        else csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
+        RV_LAUNCHED("csr_scatter_kernel");
+        return;
+    }
     const unsigned cap = L.cap_total;
     {
         size_t temp = sb.scan_temp_bytes;
@@ -770,7 +787,7 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
     const long long nb_threads = (long long)L.m_bound * (L.d + 1);
     lattice_neighbours_kernel<<<dim3((unsigned)((nb_threads + 255) / 256)), dim3(256), 0, s>>>(L);
     RV_LAUNCHED("lattice_compact_kernel / lattice_neighbours_kernel");
-    if (csr_fast_path(L) && sb.block_hist) {
+    if (fast) {
         const int mcap = (int)((L.cap_f_mask + 1) / 2);
         const int wbpf = (L.N + L.cs_pix - 1) / L.cs_pix;
         const long long waves = (long long)wbpf * L.n_frames;
@@ -780,11 +797,8 @@ void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_ent
         const int n_groups = (mcap + 63) / 64;
         csr_total_kernel<<<dim3((unsigned)(L.n_frames * n_groups)), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap, n_groups);
         csr_scan_kernel<<<dim3((unsigned)(L.n_frames * n_groups)), dim3(1024), 0, s>>>(L, sb.block_hist, wbpf, mcap, n_groups);
-        if (L.d == 6) csr_scatter_kernel<7><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        else if (L.d == 5) csr_scatter_kernel<6><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        else if (L.d == 2) csr_scatter_kernel<3><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        else csr_pass_kernel<true><<<grid, block, lds, s>>>(L, sb.block_hist, wbpf, mcap);
-        RV_LAUNCHED("csr_pass_kernel / csr_scan_kernel / csr_scatter_kernel");
+        RV_LAUNCHED("csr_count_kernel / csr_total_kernel / csr_scan_kernel");
+        if (phase == 0) launch_lattice_finish(L, sb, n_entries, s, 2);
     } else {
         lattice_remap_kernel<<<dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s>>>(L, sb.keys_in, sb.vals_in, n_entries);
         // stable radix sort by vertex id: equal keys keep ascending entry (= point) order

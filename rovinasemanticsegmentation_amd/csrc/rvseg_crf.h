@@ -112,7 +112,7 @@ struct SortBuffers {
 
 void launch_fill_int(int* p, int v, long long n, hipStream_t s);
 void launch_lattice_points(const LatticeDev& L, const FeatureSource& fs, hipStream_t s);
-void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s);
+void launch_lattice_finish(const LatticeDev& L, SortBuffers& sb, long long n_entries, hipStream_t s, int phase = 0);
 size_t sort_temp_bytes(long long n_entries, int key_bits);
 size_t scan_temp_bytes(unsigned cap);
 bool csr_fast_path(const LatticeDev& L);

@@ -295,12 +295,13 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
     tr("memsets");
     launch_lattice_points(L, fs, s);
     tr("points");
-    launch_lattice_finish(L, b.sb, b.n_entries, s);
+    // the splat's band schedule needs the lists' bounds (count / scan) and the launch order, not the lists themselves: it
+    // is planned beside the scatter and the normaliser
+    launch_lattice_finish(L, b.sb, b.n_entries, s, b.resident_on ? 1 : 0);
     tr("finish");
     rvseg_status st;
     bool plan_forked = false;
     if (b.resident_on) {
-        // the splat's band schedule needs the sorted lists only, like the normaliser below: it is planned beside it
         if ((st = second_stream(ctx, cs)) != RVSEG_OK) return st;
         RV_HIP(ctx, hipEventRecord(cs->layer_fork, s));
         RV_HIP(ctx, hipStreamWaitEvent(cs->layer_stream, cs->layer_fork, 0));
@@ -309,6 +310,7 @@ static rvseg_status lattice_build(rvseg_ctx* ctx, CrfState* cs, LatticeBufs& b, 
         RV_HIP(ctx, hipEventRecord(cs->layer_join, cs->layer_stream));
         plan_forked = true;
         tr("resident plan");
+        launch_lattice_finish(L, b.sb, b.n_entries, s, 2);   // the scatter (counting-sort path)
     }
     st = values_reserve(ctx, cs, L.m_bound, 1);
     if (st != RVSEG_OK) { if (plan_forked) (void)hipStreamWaitEvent(s, cs->layer_join, 0); return st; }
